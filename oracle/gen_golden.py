@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE — regenerate tests/golden/ from the REAL reference.
+
+Runs oracle/_ref/ref_harness (christang/alignment-algos compiled in place from
+/root/reference by oracle/Makefile) on seeded synthetic inputs and stores its outputs:
+
+  tests/golden/aa_cases.json   metadata, scores (as uint32 bit patterns), pair lists, gapped strings
+  tests/golden/aa_cases.npz    full score / pointer / similarity matrices of the small cases
+
+Only this container has /root/reference; the fixtures are what travels.  Inputs are
+regenerated from seeds by aln_amd.synth (std::mt19937-compatible), but the sequences are
+also stored so the fixtures are self-contained.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "alignment-algos_amd"))
+import orc  # noqa: E402  (only for make_subopt_regions)
+import refrun  # noqa: E402
+from aln_amd.synth import MT19937, homolog_pair, random_pair, residues  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def bits(x):
+    return int(np.float32(x).view(np.uint32))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def ali_json(a):
+    d = {"score": bits(a["score"]), "identity": bits(a["identity"]), "uid": a["uid"],
+         "pairs": a["pairs"].reshape(-1).tolist(), "annot": a["annot"]}
+    if "qstr" in a:
+        d["qstr"] = a["qstr"]
+    return d
+
+
+def set_json(s, full_limit=None):
+    """Alignments past `full_limit` keep score/uid and sha256 digests of their pair list and query line."""
+    alis = []
+    for k, a in enumerate(s["alis"]):
+        if full_limit is None or k < full_limit:
+            alis.append(ali_json(a))
+        else:
+            alis.append({"score": bits(a["score"]), "identity": bits(a["identity"]), "uid": a["uid"],
+                         "pairs_sha": sha(a["pairs"].astype(np.int32)),
+                         "qstr_sha": hashlib.sha256(a.get("qstr", "").encode()).hexdigest()})
+    d = {"n": s["n"], "alis": alis}
+    if "tstr" in s:
+        d["tstr"] = s["tstr"]
+    return d
+
+
+def main():
+    if not refrun.available():
+        raise SystemExit("oracle/_ref/ref_harness missing: run `make -C oracle` where /root/reference exists")
+    cases = []
+    arrays = {}
+
+    def add(name, q, t, mode, gi, ge, direction, ops, full, extra=None):
+        r = refrun.run_aa(q, t, mode, gi, ge, direction, ops=["dump"] + list(ops))
+        c = {"name": name, "q": q, "t": t, "mode": mode, "gi": gi, "ge": ge, "dir": direction}
+        if extra:
+            c.update(extra)
+        if "throw" in r:
+            c["throw"] = r["throw"]
+        if "dim" in r:
+            c["sha"] = {"H": sha(r["H"]), "PQ": sha(r["PQ"]), "PT": sha(r["PT"])}
+            c["corner"] = bits(r["H"][-1, -1])
+            c["origin"] = bits(r["H"][0, 0])
+            if full:
+                for k in ("H", "PQ", "PT", "S"):
+                    arrays["%s/%s" % (name, k)] = r[k]
+        c["sets"] = {k: set_json(v, None if full else 6) for k, v in r["sets"].items()}
+        cases.append(c)
+
+    # A. known answers of SURVEY.md App. C
+    for (mode, gi, ge) in ((3, 11, 1), (1, 11, 1), (4, 4.73, 0.34)):
+        add("known_m%d" % mode, "PAWHEAE", "HEAGAWGHEE", mode, gi, ge, "fwd",
+            ["opt", "cw", 10, 0.3, "1" * 12, "ucw", 10, 0.3], True)
+
+    # B. small random pairs, every align_t, both directions, integer and non-integer gaps (+ empty / 1-residue sequences)
+    rng = np.random.RandomState(20260)
+    lens = [(0, 0), (0, 7), (5, 0), (1, 1), (1, 9), (8, 1), (2, 2)] + [(int(rng.randint(3, 34)), int(rng.randint(3, 34))) for _ in range(7)]
+    for n, (ql, tl) in enumerate(lens):
+        g = MT19937(7000 + n)
+        q, t = residues(g, ql), residues(g, tl)
+        for mode in range(5):
+            for (gi, ge) in ((11, 1), (4.73, 0.34)):
+                for d in ("fwd", "rev"):
+                    add("small%02d_m%d_g%d_%s" % (n, mode, int(gi), d), q, t, mode, gi, ge, d, ["opt"], True)
+
+    # C. near-optimal enumeration on mutated homologs
+    for n in range(10):
+        ln = int(rng.randint(12, 64))
+        q, t = homolog_pair(8000 + n, ln, sub_rate=0.2, indel=3)
+        T = len(t) + 2
+        for mode in (1, 3, 4):
+            gi, ge = ((11, 1), (4.73, 0.34))[n % 2]
+            regs = int(rng.randint(1, 8))
+            fl = "".join(str(int(x)) for x in orc.make_subopt_regions(T, regs))
+            delta = float(rng.choice([0.01, 0.05, 0.1, 0.3]))
+            nsub = int(rng.choice([3, 20, 40]))
+            add("enum%02d_m%d" % (n, mode), q, t, mode, gi, ge, "fwd",
+                ["opt", "cw", nsub, delta, fl, "ucw", nsub, delta], True,
+                {"nsub": nsub, "delta": delta, "flags": fl})
+
+    # D. 130 x 171 random pairs, hashes + optimal
+    for n in range(3):
+        q, t = random_pair(9000 + n, 130, 171)
+        for mode in (1, 3, 4):
+            add("mid%02d_m%d" % (n, mode), q, t, mode, 11, 1, "fwd", ["opt"], False)
+
+    # E. config 1: seed 12345, two 300-aa sequences (query drawn first), modes 3/4/1, both gap settings
+    q, t = random_pair(12345, 300)
+    fl = "".join(str(int(x)) for x in orc.make_subopt_regions(302, 10))
+    for mode in (3, 4, 1):
+        for (gi, ge) in ((11, 1), (4.73, 0.34)):
+            add("c1_m%d_g%d" % (mode, int(gi)), q, t, mode, gi, ge, "fwd", ["opt", "cw", 256, 0.05, fl], False,
+                {"nsub": 256, "delta": 0.05, "flags": fl})
+    # a 300-aa homolog pair for long tracebacks + big enumerations (C4-shaped, small)
+    q, t = homolog_pair(4242, 300)
+    for mode in (3, 1):
+        add("c4_m%d" % mode, q, t, mode, 11, 1, "fwd", ["opt", "cw", 256, 0.05, fl], False,
+            {"nsub": 256, "delta": 0.05, "flags": fl})
+
+    # F. sub-matrix builds (7-arg ctor) + Optimal_Subali
+    subs = []
+    for n in range(16):
+        g = MT19937(9500 + n)
+        ql, tl = int(rng.randint(6, 26)), int(rng.randint(6, 26))
+        q, t = residues(g, ql), residues(g, tl)
+        Q, T = ql + 2, tl + 2
+        q1 = int(rng.randint(0, Q - 2)); q2 = int(rng.randint(q1 + 1, Q))
+        t1 = int(rng.randint(0, T - 2)); t2 = int(rng.randint(t1 + 1, T))
+        mode = (1, 3, 4)[n % 3]
+        for d in ("fwd", "rev"):
+            r = refrun.run_sub(q, t, mode, 11, 1, d, q1, t1, q2, t2)
+            name = "sub%02d_%s" % (n, d)
+            c = {"name": name, "q": q, "t": t, "mode": mode, "gi": 11, "ge": 1, "dir": d, "bounds": [q1, q2, t1, t2]}
+            for k in ("H", "PQ", "PT"):
+                arrays["%s/%s" % (name, k)] = r[k]
+            if "subali" in r:
+                c["subali"] = {"score": bits(r["subali"]["score"]), "pairs": r["subali"]["pairs"].reshape(-1).tolist()}
+            if "throw" in r:
+                c["throw"] = r["throw"]
+            subs.append(c)
+
+    with open(os.path.join(GOLD, "aa_cases.json"), "w") as f:
+        json.dump({"generator": "oracle/gen_golden.py via oracle/_ref/ref_harness (real reference, g++ -O2, no -ffast-math)",
+                   "cases": cases, "subs": subs}, f, separators=(",", ":"))
+    np.savez_compressed(os.path.join(GOLD, "aa_cases.npz"), **arrays)
+    print("cases", len(cases), "subs", len(subs), "arrays", len(arrays))
+
+
+if __name__ == "__main__":
+    main()
