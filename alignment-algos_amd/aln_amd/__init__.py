@@ -1,0 +1,292 @@
+"""aln_amd — thin ctypes binding of libalnhip.so (include/aln_hip.h), used by tests/ and bench.py.
+
+The product is the C-ABI shared library built from csrc/*.hip for gfx950; this module only loads it
+and marshals numpy arrays.  There is NO CPU fallback: if the library is missing or there is no GPU the
+calls fail loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(PKG_DIR, "libalnhip.so")
+
+GLOBAL_LOCAL, GLOBAL, LOCAL_GLOBAL, LOCAL, SEMI_LOCAL = 0, 1, 2, 3, 4
+FWD, REV = 1, 2
+GAP_AFFINE_CONST, GAP_AFFINE_TPOS_MIN = 0, 1
+SIM_SUBMATRIX, SIM_MATRIX, SIM_HMAP2 = 0, 1, 2
+DP_AUTO, DP_EXACT, DP_FAST = 0, 1, 2
+ENUM_CW, ENUM_UCW = 0, 1
+
+E_BOUNDS, E_GAPSTYLE, E_STARTPAIR, E_RESIDUE, E_ARG, E_HIP, E_NOMEM, E_TOO_LONG, E_NOT_INTEGRAL, E_STATE, E_OVERFLOW = range(-1, -12, -1)
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+
+
+class AlnSeqs(C.Structure):
+    _fields_ = [("n_seqs", C.c_int32), ("offsets", _lp), ("residues", C.c_char_p)]
+
+
+class AlnSubmatrix(C.Structure):
+    _fields_ = [("n", C.c_int32), ("alphabet", C.c_char_p), ("table", _fp)]
+
+
+class AlnProfiles(C.Structure):
+    _fields_ = [("aa", _fp), ("sse", _fp), ("conf", _fp)]
+
+
+class AlnGap(C.Structure):
+    _fields_ = [("model", C.c_int32), ("align_type", C.c_int32), ("gap_init", C.c_float), ("gap_extn", C.c_float),
+                ("t_gap_init", _fp), ("t_gap_extn", _fp)]
+
+
+class AlnSim(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("sub", AlnSubmatrix), ("planes", _fp), ("plane_off", _lp),
+                ("q_prof", AlnProfiles), ("t_prof", AlnProfiles), ("alpha", C.c_float), ("zero_shift", C.c_float),
+                ("normalize", C.c_int32)]
+
+
+class AlnNoa(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("number_suboptimal", C.c_int32), ("delta_ratio", C.c_float), ("user_limit", C.c_uint32)]
+
+
+class AlnAlignment(C.Structure):
+    _fields_ = [("score", C.c_float), ("identity", C.c_float), ("uid", C.c_int32), ("n_pairs", C.c_int32), ("pair_off", C.c_int64)]
+
+
+EXPORTS = [
+    "aln_ctx_create", "aln_ctx_destroy", "aln_error_string", "aln_last_error", "aln_ctx_synchronize", "aln_has_gfx950",
+    "aln_batch_create", "aln_batch_destroy", "aln_batch_n_pairs", "aln_batch_device_bytes", "aln_batch_dp",
+    "aln_batch_reevaluate", "aln_batch_dp_kernel_name", "aln_batch_dp_sub", "aln_batch_get_cells", "aln_batch_get_sim",
+    "aln_batch_get_corner_scores", "aln_batch_optimal", "aln_batch_optimal_subali", "aln_batch_enumerate", "aln_identity",
+    "aln_gapped_length", "aln_gapped_strings", "aln_batch_last_dp_ms", "aln_batch_dp_algorithmic_bytes", "aln_batch_cells",
+]
+
+_LIB = None
+
+
+class AlnError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "%s (aln status %d)" % (msg, code))
+        self.code = code
+
+
+def build_library():
+    subprocess.check_call(["make", "-s", "-C", PKG_DIR, "-j8"])
+
+
+def lib():
+    """Load libalnhip.so (never a fallback)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libalnhip.so not built: run `make -C alignment-algos_amd` (hipcc --offload-arch=gfx950)")
+        L = C.CDLL(LIB_PATH)
+        L.aln_error_string.restype = C.c_char_p
+        L.aln_last_error.restype = C.c_char_p
+        L.aln_last_error.argtypes = [C.c_void_p]
+        L.aln_batch_dp_kernel_name.restype = C.c_char_p
+        L.aln_batch_dp_kernel_name.argtypes = [C.c_void_p]
+        L.aln_identity.restype = C.c_float
+        for f in ("aln_batch_device_bytes", "aln_batch_dp_algorithmic_bytes", "aln_batch_cells"):
+            getattr(L, f).restype = C.c_int64
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.aln_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.aln_ctx_destroy.argtypes = [C.c_void_p]
+        L.aln_ctx_synchronize.argtypes = [C.c_void_p]
+        L.aln_batch_create.argtypes = [C.c_void_p, C.POINTER(AlnSeqs), C.POINTER(AlnSeqs), C.c_int32, _ip, _ip, C.c_int32, C.POINTER(C.c_void_p)]
+        L.aln_batch_destroy.argtypes = [C.c_void_p]
+        L.aln_batch_n_pairs.argtypes = [C.c_void_p]
+        L.aln_batch_dp.argtypes = [C.c_void_p, C.POINTER(AlnSim), C.POINTER(AlnGap), C.c_int32, C.c_int32, C.c_int32]
+        L.aln_batch_reevaluate.argtypes = [C.c_void_p]
+        L.aln_batch_dp_sub.argtypes = [C.c_void_p, C.POINTER(AlnSim), C.POINTER(AlnGap), C.c_int32, _ip]
+        L.aln_batch_get_cells.argtypes = [C.c_void_p, C.c_int32, _fp, _ip, _ip]
+        L.aln_batch_get_sim.argtypes = [C.c_void_p, C.c_int32, _fp]
+        L.aln_batch_get_corner_scores.argtypes = [C.c_void_p, _fp]
+        L.aln_batch_optimal.argtypes = [C.c_void_p, _fp, _ip, _ip, C.c_int32, _ip]
+        L.aln_batch_optimal_subali.argtypes = [C.c_void_p, _fp, _ip, _ip, C.c_int32, _ip]
+        L.aln_batch_enumerate.argtypes = [C.c_void_p, C.c_int32, C.POINTER(AlnNoa), C.POINTER(C.c_uint8), C.POINTER(AlnAlignment),
+                                          C.c_int32, _ip, C.c_int64, _ip]
+        L.aln_identity.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, _ip, C.c_int32]
+        L.aln_gapped_length.argtypes = [C.c_int32, C.POINTER(AlnAlignment), C.c_int32, _ip]
+        L.aln_gapped_strings.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(AlnAlignment), C.c_int32, _ip,
+                                         C.c_char_p, C.c_char_p, C.c_int32]
+        L.aln_batch_last_dp_ms.argtypes = [C.c_void_p, _fp]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc, ctx=None):
+    if rc != 0:
+        msg = lib().aln_error_string(rc).decode()
+        if ctx is not None and rc == E_HIP:
+            msg += ": " + lib().aln_last_error(ctx).decode()
+        raise AlnError(rc, msg)
+
+
+def _f(a):
+    return a.ctypes.data_as(_fp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+class SeqPool:
+    """A pool of sequences; each entry is given WITHOUT sentinels and stored as '^' + s + '$'."""
+
+    def __init__(self, seqs):
+        self.seqs = ["^" + s + "$" for s in seqs]
+        self.offsets = np.zeros(len(seqs) + 1, dtype=np.int64)
+        np.cumsum([len(s) for s in self.seqs], out=self.offsets[1:])
+        self.blob = "".join(self.seqs).encode()
+        self.c = AlnSeqs(len(seqs), self.offsets.ctypes.data_as(_lp), self.blob)
+
+
+class Context:
+    def __init__(self, device=0, stream=None):
+        self.h = C.c_void_p()
+        _check(lib().aln_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self.h)))
+
+    def synchronize(self):
+        _check(lib().aln_ctx_synchronize(self.h), self.h)
+
+    def close(self):
+        if self.h:
+            lib().aln_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """Many DPMatrix objects resident in HBM (aln_batch)."""
+
+    def __init__(self, ctx, queries, templates, q_idx=None, t_idx=None, score_only=False):
+        self.ctx = ctx
+        self.qpool = queries if isinstance(queries, SeqPool) else SeqPool(queries)
+        self.tpool = templates if isinstance(templates, SeqPool) else SeqPool(templates)
+        if q_idx is None:
+            q_idx = np.arange(len(self.qpool.seqs))
+            t_idx = np.arange(len(self.tpool.seqs))
+        self.q_idx = np.ascontiguousarray(q_idx, dtype=np.int32)
+        self.t_idx = np.ascontiguousarray(t_idx, dtype=np.int32)
+        self.n = len(self.q_idx)
+        self.h = C.c_void_p()
+        _check(lib().aln_batch_create(ctx.h, C.byref(self.qpool.c), C.byref(self.tpool.c), self.n, _i(self.q_idx), _i(self.t_idx),
+                                      int(score_only), C.byref(self.h)), ctx.h)
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            lib().aln_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def dims(self, p):
+        return len(self.qpool.seqs[self.q_idx[p]]), len(self.tpool.seqs[self.t_idx[p]])
+
+    # --- DP ---------------------------------------------------------------------------------
+    def _gap(self, align_type, gi, ge, tgi=None, tge=None):
+        g = AlnGap()
+        g.align_type = int(align_type)
+        g.gap_init = float(np.float32(gi))
+        g.gap_extn = float(np.float32(ge))
+        if tgi is not None:
+            g.model = GAP_AFFINE_TPOS_MIN
+            a = np.ascontiguousarray(tgi, dtype=np.float32)
+            b = np.ascontiguousarray(tge, dtype=np.float32)
+            self._keep += [a, b]
+            g.t_gap_init, g.t_gap_extn = _f(a), _f(b)
+        else:
+            g.model = GAP_AFFINE_CONST
+        return g
+
+    def dp_submatrix(self, alphabet, table, align_type, gi, ge, direction=FWD, algo=DP_AUTO, bug_b4=False, tgi=None, tge=None):
+        s = AlnSim()
+        s.kind = SIM_SUBMATRIX
+        tab = np.ascontiguousarray(table, dtype=np.float32)
+        ab = alphabet.encode()
+        s.sub = AlnSubmatrix(len(alphabet), ab, _f(tab))
+        g = self._gap(align_type, gi, ge, tgi, tge)
+        _check(lib().aln_batch_dp(self.h, C.byref(s), C.byref(g), direction, algo, int(bug_b4)), self.ctx.h)
+
+    def dp_simmatrix(self, planes, align_type, gi, ge, direction=FWD, algo=DP_AUTO, bug_b4=False, tgi=None, tge=None):
+        """planes: list of Q x T float32 arrays, one per pair."""
+        flat = [np.ascontiguousarray(p, dtype=np.float32).reshape(-1) for p in planes]
+        off = np.zeros(len(flat) + 1, dtype=np.int64)
+        np.cumsum([len(p) for p in flat], out=off[1:])
+        blob = np.concatenate(flat) if flat else np.zeros(1, np.float32)
+        s = AlnSim()
+        s.kind = SIM_MATRIX
+        s.planes = _f(blob)
+        s.plane_off = off.ctypes.data_as(_lp)
+        g = self._gap(align_type, gi, ge, tgi, tge)
+        _check(lib().aln_batch_dp(self.h, C.byref(s), C.byref(g), direction, algo, int(bug_b4)), self.ctx.h)
+
+    def reevaluate(self):
+        _check(lib().aln_batch_reevaluate(self.h), self.ctx.h)
+
+    def kernel_name(self):
+        return lib().aln_batch_dp_kernel_name(self.h).decode()
+
+    def last_dp_ms(self):
+        ms = C.c_float(0)
+        _check(lib().aln_batch_last_dp_ms(self.h, C.byref(ms)), self.ctx.h)
+        return ms.value
+
+    def cells(self):
+        return lib().aln_batch_cells(self.h)
+
+    def algorithmic_bytes(self):
+        return lib().aln_batch_dp_algorithmic_bytes(self.h)
+
+    def device_bytes(self):
+        return lib().aln_batch_device_bytes(self.h)
+
+    # --- results -----------------------------------------------------------------------------
+    def get_cells(self, p):
+        Q, T = self.dims(p)
+        D = np.empty((Q, T), dtype=np.float32)
+        PQ = np.empty((Q, T), dtype=np.int32)
+        PT = np.empty((Q, T), dtype=np.int32)
+        _check(lib().aln_batch_get_cells(self.h, p, _f(D), _i(PQ), _i(PT)), self.ctx.h)
+        return D, PQ, PT
+
+    def get_sim(self, p):
+        Q, T = self.dims(p)
+        S = np.empty((Q, T), dtype=np.float32)
+        _check(lib().aln_batch_get_sim(self.h, p, _f(S)), self.ctx.h)
+        return S
+
+    def corner_scores(self):
+        s = np.empty(self.n, dtype=np.float32)
+        _check(lib().aln_batch_get_corner_scores(self.h, _f(s)), self.ctx.h)
+        return s
+
+    def optimal(self, want_pairs=True, subali=False):
+        """-> scores[n], list of pair arrays (list order), status[n]"""
+        scores = np.empty(self.n, dtype=np.float32)
+        cnt = np.zeros(self.n, dtype=np.int32)
+        status = np.zeros(self.n, dtype=np.int32)
+        if not hasattr(self, "_stride"):
+            self._stride = max(min(max(self.dims(p)[0] for p in range(self.n)), max(self.dims(p)[1] for p in range(self.n))) + 3, 4) if self.n else 4
+        stride = self._stride
+        pairs = np.zeros((self.n, stride, 2), dtype=np.int32) if want_pairs else None
+        fn = lib().aln_batch_optimal_subali if subali else lib().aln_batch_optimal
+        _check(fn(self.h, _f(scores), _i(cnt), _i(pairs) if want_pairs else None, stride, _i(status)), self.ctx.h)
+        lists = [pairs[p, :cnt[p]].copy() for p in range(self.n)] if want_pairs else None
+        return scores, lists, status

@@ -1,0 +1,437 @@
+// aln_api.hip — the extern "C" boundary of libalnhip.so: contexts, resident batches, dispatch, getters.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "aln_internal.h"
+
+using namespace aln;
+
+namespace {
+
+const char* kErrStr(int s) {
+  switch (s) {
+    case ALN_OK: return "ok";
+    case ALN_E_BOUNDS: return "Illegal bounds building DPM";          // dpmatrix.h:361
+    case ALN_E_GAPSTYLE: return "Illegal gap style";                   // aasubalib.h:46
+    case ALN_E_STARTPAIR: return "Illegal alignment start pair";       // optimal.h:74
+    case ALN_E_RESIDUE: return "Residue not in substitution matrix alphabet";
+    case ALN_E_ARG: return "Bad argument";
+    case ALN_E_HIP: return "HIP runtime error";
+    case ALN_E_NOMEM: return "Out of memory";
+    case ALN_E_TOO_LONG: return "Sequence too long for this build";
+    case ALN_E_NOT_INTEGRAL: return "Scores or gap penalties are not small integers";
+    case ALN_E_STATE: return "Call order error (no DP built)";
+    case ALN_E_OVERFLOW: return "Output buffer too small";
+    default: return "unknown";
+  }
+}
+
+template <class T>
+int dalloc(aln_ctx* ctx, T** p, size_t n) {
+  *p = nullptr;
+  if (n == 0) n = 1;
+  ALN_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
+  return ALN_OK;
+}
+
+bool valid_align_type(int a) { return a >= 0 && a <= 4; }
+
+}  // namespace
+
+extern "C" {
+
+const char* aln_error_string(int status) { return kErrStr(status); }
+const char* aln_last_error(const aln_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+int aln_has_gfx950(void) { return 1; }
+
+int aln_ctx_create(int device_id, void* stream, aln_ctx** out) {
+  if (!out) return ALN_E_ARG;
+  *out = nullptr;
+  aln_ctx* c = new aln_ctx();
+  c->device = device_id;
+  c->stream = nullptr;
+  c->own_stream = false;
+  if (hipSetDevice(device_id) != hipSuccess) { delete c; return ALN_E_HIP; }
+  if (stream) c->stream = reinterpret_cast<hipStream_t>(stream);
+  else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ALN_E_HIP; }
+    c->own_stream = true;
+  }
+  *out = c;
+  return ALN_OK;
+}
+
+void aln_ctx_destroy(aln_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int aln_ctx_synchronize(aln_ctx* ctx) {
+  if (!ctx) return ALN_E_ARG;
+  ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return ALN_OK;
+}
+
+int aln_batch_create(aln_ctx* ctx, const aln_seqs* queries, const aln_seqs* templates, int32_t n_pairs,
+                     const int32_t* q_idx, const int32_t* t_idx, int32_t score_only, aln_batch** out) {
+  if (!ctx || !queries || !templates || !out || n_pairs < 0 || (n_pairs > 0 && (!q_idx || !t_idx))) return ALN_E_ARG;
+  *out = nullptr;
+  ALN_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  aln_batch* b = new aln_batch();
+  b->ctx = ctx;
+  b->n_pairs = n_pairs;
+  b->score_only = score_only != 0;
+  b->d_pairs = nullptr; b->d_qcodes = nullptr; b->d_tcodes = nullptr; b->d_H = nullptr; b->d_P = nullptr; b->d_S = nullptr;
+  b->d_res = nullptr; b->d_table32 = nullptr; b->d_tablef = nullptr; b->d_tgi = nullptr; b->d_tge = nullptr;
+  b->d_path = nullptr; b->d_bounds = nullptr; b->ev0 = nullptr; b->ev1 = nullptr;
+  b->have_dp = false; b->have_sub = false; b->islocal = false; b->alpha_n = 0;
+  b->q_offsets.assign(queries->offsets, queries->offsets + queries->n_seqs + 1);
+  b->t_offsets.assign(templates->offsets, templates->offsets + templates->n_seqs + 1);
+  b->q_total = b->q_offsets.back();
+  b->t_total = b->t_offsets.back();
+  b->q_res.assign(queries->residues, queries->residues + b->q_total);
+  b->t_res.assign(templates->residues, templates->residues + b->t_total);
+  b->h_pairs.resize(n_pairs);
+  b->maxQ = 0; b->maxT = 0; b->cells = 0;
+  int64_t off = 0;
+  for (int p = 0; p < n_pairs; ++p) {
+    int qi = q_idx[p], ti = t_idx[p];
+    if (qi < 0 || qi >= queries->n_seqs || ti < 0 || ti >= templates->n_seqs) { delete b; return ALN_E_ARG; }
+    PairDesc& d = b->h_pairs[p];
+    int64_t Q = b->q_offsets[qi + 1] - b->q_offsets[qi], T = b->t_offsets[ti + 1] - b->t_offsets[ti];
+    if (Q < 2 || T < 2) { delete b; return ALN_E_ARG; }          // every sequence carries '^' and '$'
+    if (Q > kMaxLen || T > kMaxLen) { delete b; return ALN_E_TOO_LONG; }
+    d.Q = (int)Q; d.T = (int)T; d.ld = ((int)T + 3) & ~3;
+    d.q_seq = qi; d.t_seq = ti;
+    d.q_off = b->q_offsets[qi]; d.t_off = b->t_offsets[ti];
+    d.plane_off = off;
+    d.q0 = 0; d.q1 = d.Q - 1; d.t0 = 0; d.t1 = d.T - 1;
+    if (!b->score_only) off += (int64_t)d.Q * d.ld;
+    b->maxQ = std::max(b->maxQ, d.Q); b->maxT = std::max(b->maxT, d.T);
+    b->cells += (int64_t)(d.Q - 2) * (d.T - 2);
+  }
+  b->plane_elems = off;
+  b->path_stride = std::min(b->maxQ, b->maxT) + 3;
+  int rc;
+#define TRY(x) if ((rc = (x)) != ALN_OK) { aln_batch_destroy(b); return rc; }
+  TRY(dalloc(ctx, &b->d_pairs, (size_t)n_pairs));
+  TRY(dalloc(ctx, &b->d_qcodes, (size_t)b->q_total));
+  TRY(dalloc(ctx, &b->d_tcodes, (size_t)b->t_total));
+  TRY(dalloc(ctx, &b->d_res, (size_t)n_pairs));
+  TRY(dalloc(ctx, &b->d_table32, 32 * 32));
+  TRY(dalloc(ctx, &b->d_tablef, 32 * 32));
+  if (!b->score_only) {
+    TRY(dalloc(ctx, &b->d_H, (size_t)off));
+    TRY(dalloc(ctx, &b->d_P, (size_t)off));
+    TRY(dalloc(ctx, &b->d_path, (size_t)n_pairs * b->path_stride * 2));
+  }
+#undef TRY
+  if (hipMemcpyAsync(b->d_pairs, b->h_pairs.data(), sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+      hipMemsetAsync(b->d_res, 0, sizeof(PairResult) * (n_pairs ? n_pairs : 1), ctx->stream) != hipSuccess ||
+      hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    ctx->last_error = "batch upload failed";
+    aln_batch_destroy(b);
+    return ALN_E_HIP;
+  }
+  *out = b;
+  return ALN_OK;
+}
+
+void aln_batch_destroy(aln_batch* b) {
+  if (!b) return;
+  hipFree(b->d_pairs); hipFree(b->d_qcodes); hipFree(b->d_tcodes); hipFree(b->d_H); hipFree(b->d_P); hipFree(b->d_S);
+  hipFree(b->d_res); hipFree(b->d_table32); hipFree(b->d_tablef); hipFree(b->d_tgi); hipFree(b->d_tge);
+  hipFree(b->d_path); hipFree(b->d_bounds);
+  if (b->ev0) hipEventDestroy(b->ev0);
+  if (b->ev1) hipEventDestroy(b->ev1);
+  delete b;
+}
+
+int32_t aln_batch_n_pairs(const aln_batch* b) { return b ? b->n_pairs : 0; }
+int64_t aln_batch_cells(const aln_batch* b) { return b ? b->cells : 0; }
+int64_t aln_batch_dp_algorithmic_bytes(const aln_batch* b) {
+  if (!b) return 0;
+  int64_t n = 0;
+  for (const PairDesc& d : b->h_pairs) n += (int64_t)d.Q * d.T;
+  return n * 8;   // fp32 score + packed pointer per cell
+}
+int64_t aln_batch_device_bytes(const aln_batch* b) {
+  if (!b) return 0;
+  int64_t n = (int64_t)sizeof(PairDesc) * b->n_pairs + b->q_total + b->t_total + (int64_t)sizeof(PairResult) * b->n_pairs;
+  if (!b->score_only) n += b->plane_elems * 8 + (int64_t)b->n_pairs * b->path_stride * 8;
+  if (b->d_S) n += b->plane_elems * 4;
+  return n;
+}
+const char* aln_batch_dp_kernel_name(const aln_batch* b) { return b ? b->kernel_name.c_str() : ""; }
+
+}  // extern "C"
+
+namespace {
+
+// residues -> codes under `alphabet`; '^' and '$' get the two sentinel codes whose table rows are zero
+int encode(const std::string& res, const int* idx, std::vector<uint8_t>& codes) {
+  codes.resize(res.size());
+  for (size_t k = 0; k < res.size(); ++k) {
+    unsigned char ch = (unsigned char)res[k];
+    int c = (ch == '^') ? kCodeHead : (ch == '$') ? kCodeTail : idx[ch];
+    if (c < 0) return ALN_E_RESIDUE;
+    codes[k] = (uint8_t)c;
+  }
+  return ALN_OK;
+}
+
+int upload_submatrix(aln_batch* b, const aln_submatrix* sub) {
+  aln_ctx* ctx = b->ctx;
+  if (!sub->alphabet || !sub->table || sub->n < 1 || sub->n > 30) return ALN_E_ARG;
+  int idx[256];
+  for (int i = 0; i < 256; ++i) idx[i] = -1;
+  for (int i = 0; i < sub->n; ++i) idx[(unsigned char)sub->alphabet[i]] = i;
+  std::vector<uint8_t> qc, tc;
+  int rc = encode(b->q_res, idx, qc);
+  if (rc) return rc;
+  rc = encode(b->t_res, idx, tc);
+  if (rc) return rc;
+  float tf[32 * 32];
+  int32_t ti[32 * 32];
+  for (int i = 0; i < 32 * 32; ++i) { tf[i] = 0.f; ti[i] = 0; }
+  for (int i = 0; i < sub->n; ++i)
+    for (int j = 0; j < sub->n; ++j) {
+      tf[i * 32 + j] = sub->table[i * sub->n + j];
+      ti[i * 32 + j] = (int32_t)sub->table[i * sub->n + j];
+    }
+  b->h_table.assign(sub->table, sub->table + sub->n * sub->n);
+  b->alpha_n = sub->n;
+  b->alphabet.assign(sub->alphabet, sub->alphabet + sub->n);
+  ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_qcodes, qc.data(), qc.size(), hipMemcpyHostToDevice, ctx->stream));
+  ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_tcodes, tc.data(), tc.size(), hipMemcpyHostToDevice, ctx->stream));
+  ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_tablef, tf, sizeof tf, hipMemcpyHostToDevice, ctx->stream));
+  ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_table32, ti, sizeof ti, hipMemcpyHostToDevice, ctx->stream));
+  ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // the staging vectors die here
+  return ALN_OK;
+}
+
+int upload_simplanes(aln_batch* b, const aln_sim* sim, bool* integral) {
+  aln_ctx* ctx = b->ctx;
+  if (!sim->planes || !sim->plane_off) return ALN_E_ARG;
+  if (!b->d_S) { int rc = dalloc(ctx, &b->d_S, (size_t)b->plane_elems); if (rc) return rc; }
+  bool integ = true;
+  for (int p = 0; p < b->n_pairs; ++p) {
+    const PairDesc& d = b->h_pairs[p];
+    const float* src = sim->planes + sim->plane_off[p];
+    for (int64_t k = 0; k < (int64_t)d.Q * d.T && integ; ++k) {
+      float v = src[k];
+      if (!(v == (float)(int)v) || fabsf(v) > 4096.f) integ = false;
+    }
+    ALN_HIP_CHECK(ctx, hipMemcpy2DAsync(b->d_S + d.plane_off, (size_t)d.ld * 4, src, (size_t)d.T * 4, (size_t)d.T * 4, d.Q,
+                                        hipMemcpyHostToDevice, ctx->stream));
+  }
+  ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  *integral = integ;
+  return ALN_OK;
+}
+
+int upload_tgaps(aln_batch* b, const aln_gap* gap) {
+  aln_ctx* ctx = b->ctx;
+  if (!gap->t_gap_init || !gap->t_gap_extn) return ALN_E_ARG;
+  if (!b->d_tgi) { int rc = dalloc(ctx, &b->d_tgi, (size_t)b->t_total); if (rc) return rc; }
+  if (!b->d_tge) { int rc = dalloc(ctx, &b->d_tge, (size_t)b->t_total); if (rc) return rc; }
+  ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_tgi, gap->t_gap_init, b->t_total * 4, hipMemcpyHostToDevice, ctx->stream));
+  ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_tge, gap->t_gap_extn, b->t_total * 4, hipMemcpyHostToDevice, ctx->stream));
+  ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return ALN_OK;
+}
+
+int run_dp(aln_batch* b, bool simplane_integral) {
+  aln_ctx* ctx = b->ctx;
+  const bool sub = b->sim_kind == ALN_SIM_SUBMATRIX;
+  bool fast = false;
+  if (b->algo != ALN_DP_EXACT && !b->have_sub && b->direction == ALN_FWD)
+    fast = fast_path_legal(b, sub ? b->h_table.data() : nullptr, b->alpha_n, &b->gap, simplane_integral);
+  if (b->algo == ALN_DP_FAST && !fast) return ALN_E_NOT_INTEGRAL;
+  ALN_HIP_CHECK(ctx, hipEventRecord(b->ev0, ctx->stream));
+  int rc = fast ? launch_dp_affine_int(b, !sub) : launch_dp_exact(b);
+  if (rc) return rc;
+  ALN_HIP_CHECK(ctx, hipEventRecord(b->ev1, ctx->stream));
+  rc = launch_dp_corner(b);
+  if (rc) return rc;
+  b->have_dp = true;
+  return ALN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int aln_batch_dp(aln_batch* b, const aln_sim* sim, const aln_gap* gap, int32_t direction, int32_t algo, int32_t bug_b4) {
+  if (!b || !sim || !gap) return ALN_E_ARG;
+  if (b->score_only) return ALN_E_ARG;
+  aln_ctx* ctx = b->ctx;
+  ALN_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (!valid_align_type(gap->align_type)) return ALN_E_GAPSTYLE;
+  if (direction != ALN_FWD && direction != ALN_REV) return ALN_E_ARG;
+  if (gap->model != ALN_GAP_AFFINE_CONST && gap->model != ALN_GAP_AFFINE_TPOS_MIN) return ALN_E_ARG;
+  b->gap = *gap;
+  b->sim_kind = sim->kind;
+  b->direction = direction;
+  b->algo = algo;
+  b->bug_b4 = bug_b4;
+  b->islocal = gap->align_type == ALN_LOCAL;                       // dpmatrix.h:155
+  b->have_sub = false;
+  for (PairDesc& d : b->h_pairs) { d.q0 = 0; d.q1 = d.Q - 1; d.t0 = 0; d.t1 = d.T - 1; }
+  b->gapdev.model = gap->model;
+  b->gapdev.align_type = gap->align_type;
+  b->gapdev.gi = gap->gap_init; b->gapdev.ge = gap->gap_extn;
+  b->gapdev.free_del = (gap->align_type == ALN_LOCAL || gap->align_type == ALN_SEMI_LOCAL || gap->align_type == ALN_LOCAL_GLOBAL);
+  b->gapdev.free_ins = (gap->align_type == ALN_LOCAL || gap->align_type == ALN_SEMI_LOCAL || gap->align_type == ALN_GLOBAL_LOCAL);
+  int rc;
+  bool integral = false;
+  if (gap->model == ALN_GAP_AFFINE_TPOS_MIN) { rc = upload_tgaps(b, gap); if (rc) return rc; }
+  if (sim->kind == ALN_SIM_SUBMATRIX) { rc = upload_submatrix(b, &sim->sub); if (rc) return rc; }
+  else if (sim->kind == ALN_SIM_MATRIX) { rc = upload_simplanes(b, sim, &integral); if (rc) return rc; }
+  else return ALN_E_ARG;
+  b->gap.t_gap_init = nullptr; b->gap.t_gap_extn = nullptr;        // host pointers are not retained
+  ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_pairs, b->h_pairs.data(), sizeof(PairDesc) * b->n_pairs, hipMemcpyHostToDevice, ctx->stream));
+  return run_dp(b, integral);
+}
+
+int aln_batch_reevaluate(aln_batch* b) {
+  if (!b) return ALN_E_ARG;
+  if (!b->have_dp) return ALN_E_STATE;
+  return run_dp(b, false);
+}
+
+int aln_batch_dp_sub(aln_batch* b, const aln_sim* sim, const aln_gap* gap, int32_t direction, const int32_t* bounds) {
+  (void)b; (void)sim; (void)gap; (void)direction; (void)bounds;
+  return ALN_E_ARG;   // filled in with the exact kernel
+}
+
+int aln_batch_last_dp_ms(aln_batch* b, float* ms) {
+  if (!b || !ms) return ALN_E_ARG;
+  if (!b->have_dp) return ALN_E_STATE;
+  ALN_HIP_CHECK(b->ctx, hipEventSynchronize(b->ev1));
+  ALN_HIP_CHECK(b->ctx, hipEventElapsedTime(ms, b->ev0, b->ev1));
+  return ALN_OK;
+}
+
+int aln_batch_get_cells(aln_batch* b, int32_t pair, float* score, int32_t* prev_q, int32_t* prev_t) {
+  if (!b || pair < 0 || pair >= b->n_pairs) return ALN_E_ARG;
+  if (!b->have_dp) return ALN_E_STATE;
+  aln_ctx* ctx = b->ctx;
+  const PairDesc& d = b->h_pairs[pair];
+  const size_t n = (size_t)d.Q * d.ld;
+  std::vector<float> h(score ? n : 0);
+  std::vector<uint32_t> p((prev_q || prev_t) ? n : 0);
+  if (score) ALN_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), b->d_H + d.plane_off, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (prev_q || prev_t) ALN_HIP_CHECK(ctx, hipMemcpyAsync(p.data(), b->d_P + d.plane_off, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < d.Q; ++i)
+    for (int j = 0; j < d.T; ++j) {
+      size_t s = (size_t)i * d.ld + j, o = (size_t)i * d.T + j;
+      if (score) score[o] = h[s];
+      if (prev_q || prev_t) {
+        uint32_t v = p[s];
+        int pq = (int)(v >> 16), pt = (int)(v & 0xFFFFu);
+        if (prev_q) prev_q[o] = (pq == 0xFFFF) ? -1 : pq;
+        if (prev_t) prev_t[o] = (pt == 0xFFFF) ? -1 : pt;
+      }
+    }
+  return ALN_OK;
+}
+
+int aln_batch_get_sim(aln_batch* b, int32_t pair, float* sim) {
+  if (!b || !sim || pair < 0 || pair >= b->n_pairs) return ALN_E_ARG;
+  if (!b->have_dp) return ALN_E_STATE;
+  aln_ctx* ctx = b->ctx;
+  const PairDesc& d = b->h_pairs[pair];
+  if (b->sim_kind == ALN_SIM_SUBMATRIX) {
+    // SimilarityMatrix of AASubstitutionEval (simmatrix.h:51-72, aasubalib.h:17-25) from the retained table
+    int idx[256];
+    for (int i = 0; i < 256; ++i) idx[i] = -1;
+    for (int i = 0; i < b->alpha_n; ++i) idx[(unsigned char)b->alphabet[i]] = i;
+    const char* q = b->q_res.data() + d.q_off;
+    const char* t = b->t_res.data() + d.t_off;
+    for (int i = 0; i < d.Q; ++i)
+      for (int j = 0; j < d.T; ++j) {
+        float v = 0.f;
+        if (i > 0 && j > 0 && i < d.Q - 1 && j < d.T - 1) {
+          int a = idx[(unsigned char)q[i]], c = idx[(unsigned char)t[j]];
+          if (a >= 0 && c >= 0) v = b->h_table[a * b->alpha_n + c];
+        }
+        sim[(size_t)i * d.T + j] = v;
+      }
+    return ALN_OK;
+  }
+  if (!b->d_S) return ALN_E_STATE;
+  ALN_HIP_CHECK(ctx, hipMemcpy2DAsync(sim, (size_t)d.T * 4, b->d_S + d.plane_off, (size_t)d.ld * 4, (size_t)d.T * 4, d.Q,
+                                      hipMemcpyDeviceToHost, ctx->stream));
+  ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return ALN_OK;
+}
+
+int aln_batch_get_corner_scores(aln_batch* b, float* scores) {
+  if (!b || !scores) return ALN_E_ARG;
+  if (!b->have_dp) return ALN_E_STATE;
+  std::vector<PairResult> r(b->n_pairs);
+  ALN_HIP_CHECK(b->ctx, hipMemcpyAsync(r.data(), b->d_res, sizeof(PairResult) * b->n_pairs, hipMemcpyDeviceToHost, b->ctx->stream));
+  ALN_HIP_CHECK(b->ctx, hipStreamSynchronize(b->ctx->stream));
+  for (int p = 0; p < b->n_pairs; ++p) scores[p] = r[p].corner;
+  return ALN_OK;
+}
+
+static int fetch_paths(aln_batch* b, float* scores, int32_t* n, int32_t* pairs, int32_t pair_stride, int32_t* status,
+                       bool corner_score) {
+  aln_ctx* ctx = b->ctx;
+  std::vector<PairResult> r(b->n_pairs);
+  ALN_HIP_CHECK(ctx, hipMemcpyAsync(r.data(), b->d_res, sizeof(PairResult) * b->n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<int32_t> path;
+  if (pairs) {
+    path.resize((size_t)b->n_pairs * b->path_stride * 2);
+    ALN_HIP_CHECK(ctx, hipMemcpyAsync(path.data(), b->d_path, path.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  int rc = ALN_OK;
+  for (int p = 0; p < b->n_pairs; ++p) {
+    if (scores) scores[p] = corner_score ? r[p].corner : r[p].best;
+    if (n) n[p] = r[p].n_path;
+    if (status) status[p] = r[p].status;
+    if (pairs) {
+      int len = r[p].n_path;
+      if (len > pair_stride) { len = pair_stride; rc = ALN_E_OVERFLOW; }
+      const int32_t* src = path.data() + (size_t)p * b->path_stride * 2;
+      int32_t* dst = pairs + (size_t)p * pair_stride * 2;
+      for (int k = 0; k < len; ++k) {          // device order is end -> start
+        dst[2 * k] = src[2 * (r[p].n_path - 1 - k)];
+        dst[2 * k + 1] = src[2 * (r[p].n_path - 1 - k) + 1];
+      }
+    }
+  }
+  return rc;
+}
+
+int aln_batch_optimal(aln_batch* b, float* scores, int32_t* n, int32_t* pairs, int32_t pair_stride, int32_t* status) {
+  if (!b) return ALN_E_ARG;
+  if (!b->have_dp || b->have_sub) return ALN_E_STATE;
+  int rc = launch_traceback(b, false);
+  if (rc) return rc;
+  return fetch_paths(b, scores, n, pairs, pair_stride, status, !b->islocal);
+}
+
+int aln_batch_optimal_subali(aln_batch* b, float* scores, int32_t* n, int32_t* pairs, int32_t pair_stride, int32_t* status) {
+  if (!b) return ALN_E_ARG;
+  if (!b->have_dp || !b->have_sub) return ALN_E_STATE;
+  int rc = launch_traceback(b, true);
+  if (rc) return rc;
+  return fetch_paths(b, scores, n, pairs, pair_stride, status, true);
+}
+
+int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* noa, const uint8_t* flags, aln_alignment* out,
+                        int32_t max_alignments, int32_t* pairs, int64_t pairs_capacity, int32_t* n_out) {
+  (void)b; (void)pair; (void)noa; (void)flags; (void)out; (void)max_alignments; (void)pairs; (void)pairs_capacity; (void)n_out;
+  return ALN_E_ARG;   // filled in with enumerate.hip
+}
+
+}  // extern "C"

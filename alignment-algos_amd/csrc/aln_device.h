@@ -1,0 +1,73 @@
+// Device-side helpers shared by the exact-arithmetic kernels (corner cell, exact DP, enumeration).
+// All float arithmetic here follows the reference's operation order; the library is compiled with
+// -ffp-contract=off so no mul+add is fused.
+#pragma once
+#include "aln_internal.h"
+
+namespace aln {
+
+__device__ __forceinline__ float clip0(float s, bool local) {   // std::max(0.f, s) of dpmatrix.h:580
+  return local ? ((0.f < s) ? s : 0.f) : s;
+}
+__device__ __forceinline__ float fminr(float a, float b) { return (b < a) ? b : a; }   // std::min(a,b)
+
+// Everything a kernel needs to evaluate similarity / deletion / insertion for one pair.
+struct EvalDev {
+  int Q, T;
+  int model, align_type;
+  float gi, ge;
+  const float* tgi;     // template-position gap arrays of THIS pair's template (AFFINE_TPOS_MIN) or nullptr
+  const float* tge;
+  // similarity
+  int sim_kind;                 // ALN_SIM_SUBMATRIX: codes + table; else plane
+  const uint8_t* qc; const uint8_t* tc;
+  const float* tablef;          // 32 x 32
+  const float* S; int ld;       // plane
+};
+
+// Evaluator::deletion — aasubalib.h:27-51 / hmap2_eval.h:41-67
+__device__ __forceinline__ float dev_deletion(const EvalDev& e, int t1, int t2) {
+  const bool free_end = (e.align_type == ALN_LOCAL || e.align_type == ALN_SEMI_LOCAL || e.align_type == ALN_LOCAL_GLOBAL);
+  if (e.model == ALN_GAP_AFFINE_CONST) {
+    int len = t2 - t1 - 1;
+    if (len < 1) return 0.f;
+    if (free_end && (t1 == 0 || t2 == e.T - 1)) return 0.f;
+    return e.gi + e.ge * (float)(len - 1);
+  } else {
+    int dist = t2 - t1;
+    if (dist < 2) return 0.f;
+    float gi = fminr(e.tgi[t1], e.tgi[t2]);
+    float ge = fminr(e.tge[t1], e.tge[t2]);
+    if (free_end && (t1 == 0 || t2 == e.T - 1)) return 0.f;
+    return gi + ge * (float)(dist - 2);
+  }
+}
+// Evaluator::insertion — aasubalib.h:53-77 / hmap2_eval.h:69-95 (coefficients from TEMPLATE positions t1,t2)
+__device__ __forceinline__ float dev_insertion(const EvalDev& e, int q1, int q2, int t1, int t2) {
+  const bool free_end = (e.align_type == ALN_LOCAL || e.align_type == ALN_SEMI_LOCAL || e.align_type == ALN_GLOBAL_LOCAL);
+  if (e.model == ALN_GAP_AFFINE_CONST) {
+    int len = q2 - q1 - 1;
+    if (len < 1) return 0.f;
+    if (free_end && (q1 == 0 || q2 == e.Q - 1)) return 0.f;
+    return e.gi + e.ge * (float)(len - 1);
+  } else {
+    int dist = q2 - q1;
+    if (dist < 2) return 0.f;
+    float gi = fminr(e.tgi[t1], e.tgi[t2]);
+    float ge = fminr(e.tge[t1], e.tge[t2]);
+    if (free_end && (q1 == 0 || q2 == e.Q - 1)) return 0.f;
+    return gi + ge * (float)(dist - 2);
+  }
+}
+// DPMatrix::getSim — SimilarityMatrix (simmatrix.h:51-72): zero borders, Evaluator::similarity inside
+__device__ __forceinline__ float dev_sim(const EvalDev& e, int i, int j) {
+  if (e.sim_kind == ALN_SIM_SUBMATRIX) {
+    if (i <= 0 || j <= 0 || i >= e.Q - 1 || j >= e.T - 1) return 0.f;
+    return e.tablef[(int)e.qc[i] * 32 + (int)e.tc[j]];
+  }
+  return e.S[(size_t)i * e.ld + j];
+}
+
+__device__ __forceinline__ uint32_t pack_ptr(int pq, int pt) { return ((uint32_t)pq << 16) | ((uint32_t)pt & 0xFFFFu); }
+
+}  // namespace aln

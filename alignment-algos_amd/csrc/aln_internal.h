@@ -1,0 +1,113 @@
+// Internal declarations shared by the HIP translation units of libalnhip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "aln_hip.h"
+
+namespace aln {
+
+constexpr uint32_t kNullPtr = 0xFFFFFFFFu;   // packed (prev_q<<16 | prev_t) of an untouched cell = (-1,-1)
+constexpr int kMaxLen = 65534;               // 16-bit packed indices, 0xFFFF reserved for DPCell::null
+constexpr int kCodeHead = 30, kCodeTail = 31;   // residue codes of '^' and '$'; alphabet codes are 0..n-1 (n <= 30)
+constexpr int kNeg = -(1 << 28);             // "-infinity" of the integer kernels (leaves headroom for subtractions)
+
+// One DPMatrix of the batch, as the kernels see it.
+struct PairDesc {
+  int32_t Q, T;          // sizes incl. sentinels
+  int32_t ld;            // row pitch of the planes in elements (T rounded up to 4 -> 16-byte aligned rows)
+  int32_t q_seq, t_seq;  // sequence indices (for per-position side arrays)
+  int64_t q_off, t_off;  // first residue of the query / template in their code pools
+  int64_t plane_off;     // first element of this pair's Q x ld planes
+  // sub-rectangle of build_subdpm (full build: 0, Q-1, 0, T-1)
+  int32_t q0, q1, t0, t1;
+};
+
+// Per-pair results kept on the device.
+struct PairResult {
+  float corner;          // score of the final cell ((q1,t1) forward, (q0,t0) reverse)
+  float best;            // find_max value (local) or corner (otherwise)
+  int32_t best_q, best_t;
+  int32_t n_path;        // traceback length (pairs), filled by the traceback kernel
+  int32_t status;        // 0 or ALN_E_STARTPAIR
+  float part_max;        // scratch: running maximum over interior cells (find_max partial)
+  uint32_t part_pos;     // scratch: packed (row<<16|col) of its first row-major occurrence
+};
+
+struct GapDev {
+  int32_t model, align_type;
+  float gi, ge;
+  const float* tgi;      // device, template pool positions
+  const float* tge;
+  int32_t free_del, free_ins;   // free end gaps for deletions / insertions (aasubalib.h:34-49,60-75)
+};
+
+}  // namespace aln
+
+struct aln_ctx {
+  int device;
+  hipStream_t stream;
+  bool own_stream;
+  std::string last_error;
+};
+
+struct aln_batch {
+  aln_ctx* ctx;
+  int32_t n_pairs;
+  bool score_only;
+  std::vector<aln::PairDesc> h_pairs;
+  std::vector<int64_t> q_offsets, t_offsets;   // host copies of the pools' offsets
+  std::string q_res, t_res;                    // host copies of residues (for host-side helpers / lowering)
+  int64_t q_total, t_total;
+  int32_t maxQ, maxT;
+  int64_t plane_elems;
+  int64_t cells;                               // sum (Q-2)(T-2)
+  // device
+  aln::PairDesc* d_pairs;
+  uint8_t* d_qcodes; uint8_t* d_tcodes;        // residue codes of the last SUBMATRIX dp
+  float* d_H; uint32_t* d_P; float* d_S;       // planes (d_S only for SIM_MATRIX / HMAP2)
+  aln::PairResult* d_res;
+  int32_t* d_table32;                          // 32x32 int substitution table (fast path)
+  float* d_tablef;                             // 32x32 float table (exact path / getSim)
+  float* d_tgi; float* d_tge;                  // AFFINE_TPOS_MIN arrays (template pool positions)
+  int32_t* d_path;                             // traceback output, n_pairs x path_stride x 2
+  int32_t path_stride;
+  int32_t* d_bounds;
+  // state of the last dp
+  bool have_dp, have_sub;
+  int32_t sim_kind, direction, algo, bug_b4;
+  aln_gap gap;                                 // host copy (pointers not retained beyond dp call)
+  aln::GapDev gapdev;
+  bool islocal;
+  std::string kernel_name;
+  hipEvent_t ev0, ev1;
+  std::vector<int32_t> h_bounds;
+  // retained similarity description for reevaluate()
+  std::vector<float> h_table; int32_t alpha_n; std::string alphabet;
+};
+
+#define ALN_HIP_CHECK(ctx, expr)                                                        \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(e_);           \
+      return ALN_E_HIP;                                                                 \
+    }                                                                                   \
+  } while (0)
+
+namespace aln {
+
+// dp_affine_int.hip
+int launch_dp_affine_int(aln_batch* b, bool use_simplane);
+bool fast_path_legal(const aln_batch* b, const float* table, int n, const aln_gap* gap, bool simplane_integral);
+// dp_corner.hip
+int launch_dp_corner(aln_batch* b);
+// traceback.hip
+int launch_traceback(aln_batch* b, bool subali);
+// dp_exact.hip
+int launch_dp_exact(aln_batch* b);
+
+}  // namespace aln

@@ -1,0 +1,223 @@
+/*
+ * aln_hip.h — C ABI of the MI355X (gfx950) alignment engine, libalnhip.so.
+ *
+ * The reference (christang/alignment-algos) has no ABI boundary: its hot path is the header
+ * template DPMatrix<S1,S2,Etype> driven by CRTP Evaluator plugins (evaluator.h:20-97) and
+ * walked by Enumerator classes (enumerator.h:20-25).  This header is the boundary a
+ * maintainer binds instead (INTEGRATION.md shows the C++ shim): each entry point names the
+ * reference interface it replaces.  Plain pointers and sizes only; the caller owns every host
+ * buffer, the library owns device memory inside aln_ctx / aln_batch.  Calls on one ctx are
+ * serialised by the caller; different ctx objects may be used from different threads.
+ *
+ * Index conventions are the reference's: a sequence includes its '^' head and '$' tail
+ * sentinels (sequence.cpp:15-16, fastaio.h:126,137), Q = query size, T = template size,
+ * matrices are Q x T row-major, DPCell::null is -1 (dpmatrix.cpp:15).
+ *
+ * Return codes: 0 = ok; negative values mirror the reference's throw sites so that a C++
+ * wrapper can rethrow the same std::string (aln_error_string()).
+ */
+#ifndef ALN_HIP_H
+#define ALN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- enums (values equal the reference's) ------------------------------------------- */
+enum aln_align_t {            /* alib.h:20-26 */
+  ALN_GLOBAL_LOCAL = 0, ALN_GLOBAL = 1, ALN_LOCAL_GLOBAL = 2, ALN_LOCAL = 3, ALN_SEMI_LOCAL = 4
+};
+enum aln_direction_t { ALN_FWD = 1, ALN_REV = 2 };   /* dpmatrix.h:23-26 */
+
+enum aln_gap_model {
+  ALN_GAP_AFFINE_CONST = 0,     /* AASubstitutionEval::deletion/insertion, aasubalib.h:27-77 */
+  ALN_GAP_AFFINE_TPOS_MIN = 1   /* Hmap2Eval / HMAPaliEval, hmap2_eval.h:41-95 (min of the two template positions) */
+};
+
+enum aln_sim_kind {
+  ALN_SIM_SUBMATRIX = 0,        /* residue codes + substitution table, aasubalib.h:17-25 + submatrix.h:36-38 */
+  ALN_SIM_MATRIX = 1,           /* caller-materialised SimilarityMatrix planes (any Evaluator::similarity + post_process) */
+  ALN_SIM_HMAP2 = 2             /* Hmap2Eval::similarity + post_process computed on the device, hmap2_eval.h:27-39,98-101 */
+};
+
+enum aln_dp_algo {
+  ALN_DP_AUTO = 0,              /* O(n^2) running-max kernel when every value is a small integer, else exact */
+  ALN_DP_EXACT = 1,             /* exact-order O(n^3) kernel: literal dpmatrix.h:447-486 arithmetic */
+  ALN_DP_FAST = 2               /* force the O(n^2) kernel; ALN_E_NOT_INTEGRAL if the proof fails */
+};
+
+enum aln_enum_kind {
+  ALN_ENUM_CW = 0,              /* ConstrainedNearOptimal, cw.h:68-284 */
+  ALN_ENUM_UCW = 1              /* UnconstrainedNearOptimal, ucw.h:64-236 */
+};
+
+enum aln_status {
+  ALN_OK = 0,
+  ALN_E_BOUNDS = -1,            /* "Illegal bounds building DPM"   dpmatrix.h:361,544,699,885 */
+  ALN_E_GAPSTYLE = -2,          /* "Illegal gap style"             aasubalib.h:46,72 */
+  ALN_E_STARTPAIR = -3,         /* "Illegal alignment start pair"  optimal.h:74 */
+  ALN_E_RESIDUE = -4,           /* residue outside the substitution alphabet (UB in submatrix.h:36-38) */
+  ALN_E_ARG = -5,               /* bad argument */
+  ALN_E_HIP = -6,               /* HIP runtime error, see aln_last_error() */
+  ALN_E_NOMEM = -7,
+  ALN_E_TOO_LONG = -8,          /* sequence longer than this build's kernels handle */
+  ALN_E_NOT_INTEGRAL = -9,      /* ALN_DP_FAST requested but scores/gaps are not small integers */
+  ALN_E_STATE = -10,            /* call order: dp before optimal/enumerate/get_cells */
+  ALN_E_OVERFLOW = -11          /* an output buffer or the enumeration pool is too small */
+};
+
+typedef struct aln_ctx aln_ctx;
+typedef struct aln_batch aln_batch;
+
+/* ---- plain descriptors ---------------------------------------------------------------- */
+
+/* A pool of sequences; replaces Sequence<elem_t>/AASequence (sequence.h:41-64, aa_seq.h:10-25).
+ * Sequence s is residues[offsets[s] .. offsets[s+1]) and INCLUDES '^' and '$'. */
+typedef struct {
+  int32_t n_seqs;
+  const int64_t* offsets;       /* n_seqs + 1 */
+  const char* residues;         /* one-letter codes (SequenceElem::olc) */
+} aln_seqs;
+
+/* SubstitutionMatrix / BlosumMatrix (submatrix.h:19-48): n x n row-major over `alphabet`. */
+typedef struct {
+  int32_t n;                    /* <= 30 */
+  const char* alphabet;
+  const float* table;
+} aln_submatrix;
+
+/* Per-position profile records for Hmap2Eval (HMAPElem, hmapalib_seq.h:28-99), one per residue of
+ * the pool, sentinels included: aa[20] (aa_profile), sse[3] (sse_values), conf (sse_confid). */
+typedef struct {
+  const float* aa;              /* total_residues x 20 */
+  const float* sse;             /* total_residues x 3  */
+  const float* conf;            /* total_residues      */
+} aln_profiles;
+
+/* Gap model + AliParams (alib.h:28-46). */
+typedef struct {
+  int32_t model;                /* aln_gap_model */
+  int32_t align_type;           /* aln_align_t */
+  float gap_init, gap_extn;     /* AFFINE_CONST: AliParams::gap_init_penalty / gap_extn_penalty */
+  const float* t_gap_init;      /* AFFINE_TPOS_MIN: per residue of the TEMPLATE pool (HMAPElem::gap_init()) */
+  const float* t_gap_extn;
+} aln_gap;
+
+/* Similarity source. */
+typedef struct {
+  int32_t kind;                 /* aln_sim_kind */
+  aln_submatrix sub;            /* ALN_SIM_SUBMATRIX */
+  const float* planes;          /* ALN_SIM_MATRIX: pair p's Q x T row-major plane starts at planes[plane_off[p]] */
+  const int64_t* plane_off;
+  aln_profiles q_prof, t_prof;  /* ALN_SIM_HMAP2 */
+  float alpha;                  /* HMAPaliParams::alpha   (hmap_eval.cpp:4)  */
+  float zero_shift;             /* HMAPaliParams::zero_shift (hmap_eval.cpp:7) */
+  int32_t normalize;            /* run post_process (z-normalise + shift) */
+} aln_sim;
+
+/* NOaliParams subset used by cw.h / ucw.h (noalib.h:18-45). */
+typedef struct {
+  int32_t kind;                 /* aln_enum_kind */
+  int32_t number_suboptimal;    /* NUM_SUBOPT; sortSet(max) */
+  float delta_ratio;            /* DELTA_RATIO */
+  uint32_t user_limit;          /* 0 = the reference's hard-coded 1000000 (cw.h:76) / 100000 (ucw.h:72) */
+} aln_noa;
+
+/* One alignment as the enumerators return it (AlignedPairList, alignment.h:52-113). */
+typedef struct {
+  float score;
+  float identity;               /* calcIdentity, alignment.h:856-865 */
+  int32_t uid;
+  int32_t n_pairs;
+  int64_t pair_off;             /* into the caller's pairs buffer, in (q,t) int32 units of 2 */
+} aln_alignment;
+
+/* ---- context ---------------------------------------------------------------------------- */
+/* stream: a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream) or NULL for a private stream. */
+int aln_ctx_create(int device_id, void* stream, aln_ctx** out);
+void aln_ctx_destroy(aln_ctx* ctx);
+const char* aln_error_string(int status);
+const char* aln_last_error(const aln_ctx* ctx);
+int aln_ctx_synchronize(aln_ctx* ctx);
+/* 1 if libalnhip.so carries gfx950 code objects (always, or the library does not load). */
+int aln_has_gfx950(void);
+
+/* ---- batch = many DPMatrix objects resident in HBM -------------------------------------- */
+/* Replaces N x `DPMatrix(query, templ, ...)` construction up to initMtxMem (dpmatrix.h:250-259):
+ * uploads both pools and the pair list (pair p aligns queries[q_idx[p]] with templates[t_idx[p]]).
+ * score_only != 0 keeps no cell planes (all-vs-all scoring): only corner / best scores are produced. */
+int aln_batch_create(aln_ctx* ctx, const aln_seqs* queries, const aln_seqs* templates,
+                     int32_t n_pairs, const int32_t* q_idx, const int32_t* t_idx,
+                     int32_t score_only, aln_batch** out);
+void aln_batch_destroy(aln_batch* b);
+int32_t aln_batch_n_pairs(const aln_batch* b);
+/* bytes of HBM held by the batch (planes + sequences + results) */
+int64_t aln_batch_device_bytes(const aln_batch* b);
+
+/* DPMatrix::build (dpmatrix.h:291-317) for every pair: pre_calculate/SimilarityMatrix as `sim` says,
+ * then the four builders (:356-1030) per direction and islocal = (align_type == local) (:155).
+ * Asynchronous on the ctx stream.  bug_b4 != 0 reproduces dpmatrix.h:868 in reverse global builds. */
+int aln_batch_dp(aln_batch* b, const aln_sim* sim, const aln_gap* gap,
+                 int32_t direction, int32_t algo, int32_t bug_b4);
+/* DPMatrix::reevaluate (dpmatrix.h:213-218): rebuild with the parameters of the last aln_batch_dp. */
+int aln_batch_reevaluate(aln_batch* b);
+/* name of the DP kernel the last aln_batch_dp launched ("dp_affine_int<...>" / "dp_exact<...>") */
+const char* aln_batch_dp_kernel_name(const aln_batch* b);
+
+/* 7-argument DPMatrix ctor / build_subdpm (dpmatrix.h:169-189, :319-353) on one bounds rectangle per
+ * pair: bounds[4*p..] = (q1_end, t1_end, q2_beg, t2_beg) in the order of the DEFINITION (B8). */
+int aln_batch_dp_sub(aln_batch* b, const aln_sim* sim, const aln_gap* gap,
+                     int32_t direction, const int32_t* bounds);
+
+/* DPMatrix::getCell for a whole pair (dpmatrix.h:230-232): score, prev_query_idx, prev_template_idx
+ * planes, Q x T row-major, untouched cells read 0 / -1 / -1 (dpmatrix.cpp:17-25).  Any pointer may be NULL. */
+int aln_batch_get_cells(aln_batch* b, int32_t pair, float* score, int32_t* prev_q, int32_t* prev_t);
+/* DPMatrix::getSim (dpmatrix.h:72-73) for a whole pair. */
+int aln_batch_get_sim(aln_batch* b, int32_t pair, float* sim);
+/* score of cell (Q-1,T-1) for forward, (0,0) for reverse builds, per pair (what global Optimal reports) */
+int aln_batch_get_corner_scores(aln_batch* b, float* scores);
+
+/* Optimal / Optimal_Rev ::enumerate (optimal.h:48-124, optimal_rev.h:44-131) for every pair:
+ * find_max + pointer traceback on the device.  pairs: n_pairs x pair_stride x 2 int32, (q,t) in list
+ * order; n[p] = list length; status[p] = 0 or ALN_E_STARTPAIR.  scores/n/status/pairs may be NULL. */
+int aln_batch_optimal(aln_batch* b, float* scores, int32_t* n, int32_t* pairs, int32_t pair_stride,
+                      int32_t* status);
+/* Optimal_Subali::enumerate (optimal_subali.h:60-84) on the rectangles of the last aln_batch_dp_sub. */
+int aln_batch_optimal_subali(aln_batch* b, float* scores, int32_t* n, int32_t* pairs,
+                             int32_t pair_stride, int32_t* status);
+
+/* ConstrainedNearOptimal / UnconstrainedNearOptimal ::enumerate (cw.h:68-92, ucw.h:64-85) for one pair
+ * of the resident batch.  The set is seeded with the pair's Optimal alignment exactly like the drivers do
+ * (aa_ali.cpp:83-89), the enumerator pushes its own uid-0 seed on top (B16), and the result is
+ * sortSet(number_suboptimal)'ed.  flags: T bytes (SuboptFlags, sflags.h:23-37), ignored for UCW.
+ * Outputs: up to max_alignments records + their pairs; *n_out = set size after sortSet. */
+int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* noa, const uint8_t* flags,
+                        aln_alignment* out, int32_t max_alignments,
+                        int32_t* pairs, int64_t pairs_capacity, int32_t* n_out);
+
+/* ---- host-side helpers with no device work (alignment.h / gstrings.h) -------------------- */
+/* AlignedPairList::calcIdentity (alignment.h:856-865). qstr/tstr include sentinels. */
+float aln_identity(const char* qstr, int32_t Q, const char* tstr, int32_t T,
+                   const int32_t* pairs, int32_t n_pairs);
+/* SequenceGaps (gstrings.h:84-164, gstrings.cpp:17-29): gapped template line and one gapped query line
+ * per alignment.  aln_gapped_length() gives the length of every line (without NUL). */
+int32_t aln_gapped_length(int32_t T, const aln_alignment* alis, int32_t n_alis, const int32_t* pairs);
+int aln_gapped_strings(const char* qstr, int32_t Q, const char* tstr, int32_t T,
+                       const aln_alignment* alis, int32_t n_alis, const int32_t* pairs,
+                       char* tline, char* qlines, int32_t stride);
+
+/* ---- measurement hooks ---------------------------------------------------------------------- */
+/* Milliseconds the device spent in the DP kernel(s) of the last aln_batch_dp, from HIP events recorded on
+ * the ctx stream around those launches; synchronises the stream. */
+int aln_batch_last_dp_ms(aln_batch* b, float* ms);
+/* algorithmic bytes per DP launch: 8 B per cell (fp32 score + packed pointer), SURVEY.md §8(d) */
+int64_t aln_batch_dp_algorithmic_bytes(const aln_batch* b);
+int64_t aln_batch_cells(const aln_batch* b);      /* sum over pairs of |q|*|t| = (Q-2)(T-2) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALN_HIP_H */

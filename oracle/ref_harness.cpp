@@ -176,10 +176,13 @@ int main(int argc, char** argv) {
       }
       return 0;
     }
+    auto tc0 = std::chrono::steady_clock::now();
     AADpm dpm(q, t, ev, dir, p.align_type);
+    auto tc1 = std::chrono::steady_clock::now();
     for (; a < argc; ++a) {
       std::string op = argv[a];
       if (op == "dump") dump_matrix(dpm);
+      else if (op == "ctime") printf("CTIME %.6f\n", std::chrono::duration<double>(tc1 - tc0).count());
       else if (op == "corner") {
         printf("CORNER %08x %08x\n", fbits(dpm.getCell(dpm.getQuerySize() - 1, dpm.getTemplateSize() - 1)->score),
                fbits(dpm.getCell(0, 0)->score));
