@@ -132,7 +132,9 @@ def test_full_size_properties(blosum62):
     assert scores[0] == 50.0 and len(lists[0]) == 20
     assert scores[0] == scores[2] and scores[1] == scores[3]
     assert scores[4] == sum(table[idx[c], idx[c]] for c in qs[4])
-    assert len(lists[4]) == 2002 and (lists[4][:, 0] == lists[4][:, 1]).all()
+    # the self-alignment reaches row 1, whose pointer is the origin: enumerate_local then stops with q_last == 0 and
+    # does NOT prepend (0,0) (optimal.h:96-104) -> (1,1) .. (2000,2000) + the tail pair
+    assert len(lists[4]) == 2001 and (lists[4][:, 0] == lists[4][:, 1]).all() and lists[4][0, 0] == 1
     # re-score every path: sum of similarities minus affine gap costs == reported score (local: interior pairs only)
     for p in range(4):
         pairs = lists[p][1:-1]          # drop (0,0) and the tail pair
