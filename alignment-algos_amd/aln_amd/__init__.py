@@ -237,6 +237,17 @@ class Batch:
         g = self._gap(align_type, gi, ge, tgi, tge)
         _check(lib().aln_batch_dp(self.h, C.byref(s), C.byref(g), direction, algo, int(bug_b4)), self.ctx.h)
 
+    def dp_sub_submatrix(self, alphabet, table, align_type, gi, ge, direction, bounds):
+        """7-argument DPMatrix ctor: bounds[p] = (q1_end, t1_end, q2_beg, t2_beg)."""
+        s = AlnSim()
+        s.kind = SIM_SUBMATRIX
+        tab = np.ascontiguousarray(table, dtype=np.float32)
+        ab = alphabet.encode()
+        s.sub = AlnSubmatrix(len(alphabet), ab, _f(tab))
+        g = self._gap(align_type, gi, ge)
+        bd = np.ascontiguousarray(bounds, dtype=np.int32).reshape(-1)
+        _check(lib().aln_batch_dp_sub(self.h, C.byref(s), C.byref(g), direction, _i(bd)), self.ctx.h)
+
     def reevaluate(self):
         _check(lib().aln_batch_reevaluate(self.h), self.ctx.h)
 

@@ -305,8 +305,25 @@ int aln_batch_reevaluate(aln_batch* b) {
 }
 
 int aln_batch_dp_sub(aln_batch* b, const aln_sim* sim, const aln_gap* gap, int32_t direction, const int32_t* bounds) {
-  (void)b; (void)sim; (void)gap; (void)direction; (void)bounds;
-  return ALN_E_ARG;   // filled in with the exact kernel
+  if (!b || !sim || !gap || !bounds) return ALN_E_ARG;
+  // validate first: the reference throws "Illegal bounds building DPM" (dpmatrix.h:360) before touching anything
+  for (int p = 0; p < b->n_pairs; ++p) {
+    const PairDesc& d = b->h_pairs[p];
+    int q0 = bounds[4 * p], t0 = bounds[4 * p + 1], q1 = bounds[4 * p + 2], t1 = bounds[4 * p + 3];
+    if (q0 < 0 || t0 < 0 || q1 >= d.Q || t1 >= d.T) return ALN_E_ARG;
+    if (q1 <= q0 || t1 <= t0) return ALN_E_BOUNDS;
+  }
+  // same parameter handling as a full build, then narrow every pair to its rectangle and use the exact kernel
+  int rc = aln_batch_dp(b, sim, gap, direction, ALN_DP_EXACT, 0);
+  if (rc) return rc;
+  for (int p = 0; p < b->n_pairs; ++p) {
+    PairDesc& d = b->h_pairs[p];
+    d.q0 = bounds[4 * p]; d.t0 = bounds[4 * p + 1]; d.q1 = bounds[4 * p + 2]; d.t1 = bounds[4 * p + 3];
+  }
+  b->have_sub = true;
+  aln_ctx* ctx = b->ctx;
+  ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_pairs, b->h_pairs.data(), sizeof(PairDesc) * b->n_pairs, hipMemcpyHostToDevice, ctx->stream));
+  return run_dp(b, false);
 }
 
 int aln_batch_last_dp_ms(aln_batch* b, float* ms) {
@@ -383,7 +400,7 @@ int aln_batch_get_corner_scores(aln_batch* b, float* scores) {
 }
 
 static int fetch_paths(aln_batch* b, float* scores, int32_t* n, int32_t* pairs, int32_t pair_stride, int32_t* status,
-                       bool corner_score) {
+                       bool corner_score, bool flip) {
   aln_ctx* ctx = b->ctx;
   std::vector<PairResult> r(b->n_pairs);
   ALN_HIP_CHECK(ctx, hipMemcpyAsync(r.data(), b->d_res, sizeof(PairResult) * b->n_pairs, hipMemcpyDeviceToHost, ctx->stream));
@@ -403,9 +420,10 @@ static int fetch_paths(aln_batch* b, float* scores, int32_t* n, int32_t* pairs, 
       if (len > pair_stride) { len = pair_stride; rc = ALN_E_OVERFLOW; }
       const int32_t* src = path.data() + (size_t)p * b->path_stride * 2;
       int32_t* dst = pairs + (size_t)p * pair_stride * 2;
-      for (int k = 0; k < len; ++k) {          // device order is end -> start
-        dst[2 * k] = src[2 * (r[p].n_path - 1 - k)];
-        dst[2 * k + 1] = src[2 * (r[p].n_path - 1 - k) + 1];
+      for (int k = 0; k < len; ++k) {          // forward builds: device order is end -> start
+        const int sk = flip ? (r[p].n_path - 1 - k) : k;
+        dst[2 * k] = src[2 * sk];
+        dst[2 * k + 1] = src[2 * sk + 1];
       }
     }
   }
@@ -417,7 +435,7 @@ int aln_batch_optimal(aln_batch* b, float* scores, int32_t* n, int32_t* pairs, i
   if (!b->have_dp || b->have_sub) return ALN_E_STATE;
   int rc = launch_traceback(b, false);
   if (rc) return rc;
-  return fetch_paths(b, scores, n, pairs, pair_stride, status, !b->islocal);
+  return fetch_paths(b, scores, n, pairs, pair_stride, status, !b->islocal, b->direction == ALN_FWD);
 }
 
 int aln_batch_optimal_subali(aln_batch* b, float* scores, int32_t* n, int32_t* pairs, int32_t pair_stride, int32_t* status) {
@@ -425,7 +443,7 @@ int aln_batch_optimal_subali(aln_batch* b, float* scores, int32_t* n, int32_t* p
   if (!b->have_dp || !b->have_sub) return ALN_E_STATE;
   int rc = launch_traceback(b, true);
   if (rc) return rc;
-  return fetch_paths(b, scores, n, pairs, pair_stride, status, true);
+  return fetch_paths(b, scores, n, pairs, pair_stride, status, true, true);
 }
 
 int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* noa, const uint8_t* flags, aln_alignment* out,

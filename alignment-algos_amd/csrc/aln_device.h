@@ -68,6 +68,26 @@ __device__ __forceinline__ float dev_sim(const EvalDev& e, int i, int j) {
   return e.S[(size_t)i * e.ld + j];
 }
 
+// A build rectangle and direction: frame coordinates (a,b) run from the origin (0,0) = (q0,t0) forward /
+// (q1,t1) reverse to the final cell (nQ,nT); a reverse build is the forward programme in the mirrored frame.
+struct Frame {
+  int q0, q1, t0, t1, rev;
+  __device__ __forceinline__ int nQ() const { return q1 - q0; }
+  __device__ __forceinline__ int nT() const { return t1 - t0; }
+  __device__ __forceinline__ int rq(int a) const { return rev ? q1 - a : q0 + a; }
+  __device__ __forceinline__ int rt(int b) const { return rev ? t1 - b : t0 + b; }
+};
+
+// gap costs between two frame positions (lo < hi in the frame); the evaluator sees real, ordered positions
+__device__ __forceinline__ float frame_del(const EvalDev& e, const Frame& f, int blo, int bhi) {
+  int x = f.rt(blo), y = f.rt(bhi);
+  return dev_deletion(e, x < y ? x : y, x < y ? y : x);
+}
+__device__ __forceinline__ float frame_ins(const EvalDev& e, const Frame& f, int alo, int ahi, int blo, int bhi) {
+  int x = f.rq(alo), y = f.rq(ahi), u = f.rt(blo), v = f.rt(bhi);
+  return dev_insertion(e, x < y ? x : y, x < y ? y : x, u < v ? u : v, u < v ? v : u);
+}
+
 __device__ __forceinline__ uint32_t pack_ptr(int pq, int pt) { return ((uint32_t)pq << 16) | ((uint32_t)pt & 0xFFFFu); }
 
 }  // namespace aln

@@ -1,11 +1,13 @@
-// dp_corner.hip — the final cell of a forward build and the end of find_max (gfx950).
+// dp_corner.hip — the final cell of a build and the end of find_max (gfx950).
 //
-// Reference: dpmatrix.h:505-534 / :655-687 (the cell (q1,t1) scans the whole last interior row and
-// column with the evaluator's end-gap rules), the two degenerate shortcuts :375-390 / :558-573, and
-// Optimal::find_max's seed rule (optimal.h:108-124).  One wave per pair; O(Q+T) reads of the finished
-// score plane, literal fp32 arithmetic (s = D; s -= g; s += S; clip), so it serves the integer fast
-// path and the exact path alike.  Candidate order = match, deletions k ascending, insertions k
-// ascending; "replace on strict >" == the first candidate reaching the maximum.
+// Reference: dpmatrix.h:505-534 / :655-687 (forward: cell (q1,t1) scans the whole last interior row and
+// column with the evaluator's end-gap rules), :844-874 / :995-1028 (reverse: cell (q0,t0)), the two
+// degenerate shortcuts :375-390 / :558-573 / :713-728 / :899-914, and the seed rule of
+// Optimal::find_max (optimal.h:108-124) / Optimal_Rev::find_max (optimal_rev.h:117-131).
+// One wave per pair; O(Q+T) reads of the finished score plane, literal fp32 arithmetic
+// (s = D; s -= g; s += S; clip), so it serves the integer fast path and the exact path alike.
+// Candidate order = match, deletions k ascending (in the build frame), insertions k ascending;
+// "replace on strict >" == the first candidate reaching the maximum.
 #include "aln_device.h"
 
 namespace aln {
@@ -15,7 +17,7 @@ __global__ __launch_bounds__(64) void dp_corner_kernel(const PairDesc* __restric
                                                        const float* __restrict__ tgi, const float* __restrict__ tge,
                                                        float* __restrict__ Hbase, uint32_t* __restrict__ Pbase,
                                                        const float* __restrict__ Sbase, PairResult* __restrict__ res,
-                                                       int islocal, int full_build) {
+                                                       int islocal, int full_build, int rev, int bug_b4) {
   const PairDesc pd = pairs[blockIdx.x];
   EvalDev e = proto;
   e.Q = pd.Q; e.T = pd.T; e.ld = pd.ld;
@@ -27,42 +29,42 @@ __global__ __launch_bounds__(64) void dp_corner_kernel(const PairDesc* __restric
   float* H = Hbase + pd.plane_off;
   uint32_t* P = Pbase + pd.plane_off;
   const int ld = pd.ld, lane = threadIdx.x;
-  const int q0 = pd.q0, q1 = pd.q1, t0 = pd.t0, t1 = pd.t1;
+  const Frame f = {pd.q0, pd.q1, pd.t0, pd.t1, rev};
+  const int nQ = f.nQ(), nT = f.nT();
   const bool local = islocal != 0;
-  const float s_initial = (lane == 0) ? 0.f : 0.f;   // build()/build_subdpm() zero the origin (dpmatrix.h:306, :333)
+  if (nQ <= 0 || nT <= 0) { if (lane == 0) res[blockIdx.x].status = ALN_E_BOUNDS; return; }
+  const int fq = f.rq(nQ), ft = f.rt(nT);         // the final cell, real coordinates
   float corner;
   uint32_t cptr;
-  if (q1 <= q0 || t1 <= t0) { if (lane == 0) res[blockIdx.x].status = ALN_E_BOUNDS; return; }
-  if (q1 == q0 + 1) {                 // dpmatrix.h:375-381 / :558-564 — no clip
-    float s = s_initial;
-    s -= dev_deletion(e, t0, t1);
-    s += dev_sim(e, q1, t1);
-    corner = s; cptr = pack_ptr(q0, t0);
-  } else if (t1 == t0 + 1) {          // :384-390 / :567-573
-    float s = s_initial;
-    s -= dev_insertion(e, q0, q1, t0, t1);
-    s += dev_sim(e, q1, t1);
-    corner = s; cptr = pack_ptr(q0, t0);
+  if (nQ == 1) {                      // boundary conditions force a deletion — no clip in any builder
+    float s = 0.f;                    // build()/build_subdpm() zero the origin (dpmatrix.h:306-307, :333-334)
+    s -= frame_del(e, f, 0, nT);
+    s += dev_sim(e, fq, ft);
+    corner = s; cptr = pack_ptr(f.rq(0), f.rt(0));
+  } else if (nT == 1) {               // ... or an insertion
+    float s = 0.f;
+    s -= frame_ins(e, f, 0, nQ, 0, 1);
+    s += dev_sim(e, fq, ft);
+    corner = s; cptr = pack_ptr(f.rq(0), f.rt(0));
   } else {
-    const float sc = dev_sim(e, q1, t1);
-    const int ndel = t1 - 1 - t0;     // k = t0+1 .. t1-1
-    const int nins = q1 - 1 - q0;     // k = q0+1 .. q1-1
+    const float sc = dev_sim(e, fq, ft);
+    const int ndel = nT - 1;          // k = 1 .. nT-1 (frame columns of row nQ-1)
+    const int nins = nQ - 1;          // k = 1 .. nQ-1 (frame rows of column nT-1)
     const int ncand = 1 + ndel + nins;
     float bs = 0.f; int bi = 0x7FFFFFFF;
     bool have = false;
     for (int idx = lane; idx < ncand; idx += 64) {
       float s;
       if (idx == 0) {
-        s = H[(size_t)(q1 - 1) * ld + (t1 - 1)] + sc;
+        s = H[(size_t)f.rq(nQ - 1) * ld + f.rt(nT - 1)] + sc;
       } else if (idx <= ndel) {
-        int k = t0 + idx;
-        s = H[(size_t)(q1 - 1) * ld + k];
-        s -= dev_deletion(e, k, t1);
+        s = H[(size_t)f.rq(nQ - 1) * ld + f.rt(idx)];
+        s -= frame_del(e, f, idx, nT);
         s += sc;
       } else {
-        int k = q0 + (idx - ndel);
-        s = H[(size_t)k * ld + (t1 - 1)];
-        s -= dev_insertion(e, k, q1, t1 - 1, t1);
+        int k = idx - ndel;
+        s = H[(size_t)f.rq(k) * ld + f.rt(nT - 1)];
+        s -= frame_ins(e, f, k, nQ, nT - 1, nT);
         s += sc;
       }
       s = clip0(s, local);
@@ -76,27 +78,32 @@ __global__ __launch_bounds__(64) void dp_corner_kernel(const PairDesc* __restric
       bs = take ? os : bs; bi = take ? oi : bi; have = have || oh;
     }
     corner = bs;
-    if (bi == 0) cptr = pack_ptr(q1 - 1, t1 - 1);
-    else if (bi <= ndel) cptr = pack_ptr(q1 - 1, t0 + bi);
-    else cptr = pack_ptr(q0 + (bi - ndel), t1 - 1);
+    if (bi == 0) cptr = pack_ptr(f.rq(nQ - 1), f.rt(nT - 1));
+    else if (bi <= ndel) cptr = pack_ptr(f.rq(nQ - 1), f.rt(bi));
+    else {
+      // dpmatrix.h:868 stores t1_m1 (= frame column 1) instead of t0_p1 in the reverse GLOBAL builder (B4)
+      int bt = (rev && !local && bug_b4) ? f.rt(1) : f.rt(nT - 1);
+      cptr = pack_ptr(f.rq(bi - ndel), bt);
+    }
   }
   if (lane == 0) {
-    H[(size_t)q1 * ld + t1] = corner;
-    P[(size_t)q1 * ld + t1] = cptr;
+    H[(size_t)fq * ld + ft] = corner;
+    P[(size_t)fq * ld + ft] = cptr;
     PairResult r = res[blockIdx.x];
     r.corner = corner;
     r.status = 0;
     if (local && full_build) {
-      // find_max (optimal.h:108-124): seed (Q-2,T-2) keeps ties, otherwise the first strictly greater cell
-      const int sq = pd.Q - 2, st = pd.T - 2;
-      const float seed = H[(size_t)sq * ld + st];
+      // find_max: the seed keeps ties, otherwise the first strictly greater cell of the scan wins.
+      // forward (optimal.h:111-113): seed (Q-2,T-2); reverse (optimal_rev.h:120-122): seed (0,0) = the final cell.
+      const int sq = rev ? fq : pd.Q - 2, st = rev ? ft : pd.T - 2;
+      const float seed = rev ? corner : H[(size_t)sq * ld + st];
       if (r.part_pos != 0xFFFFFFFFu && seed < r.part_max) {
         r.best = r.part_max; r.best_q = (int)(r.part_pos >> 16); r.best_t = (int)(r.part_pos & 0xFFFFu);
       } else {
         r.best = seed; r.best_q = sq; r.best_t = st;
       }
     } else {
-      r.best = corner; r.best_q = q1; r.best_t = t1;
+      r.best = corner; r.best_q = fq; r.best_t = ft;
     }
     res[blockIdx.x] = r;
   }
@@ -114,7 +121,7 @@ int launch_dp_corner(aln_batch* b) {
   hipLaunchKernelGGL(dp_corner_kernel, dim3(b->n_pairs), dim3(64), 0, b->ctx->stream, b->d_pairs, proto,
                      sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr,
                      tpos ? b->d_tge : nullptr, b->d_H, b->d_P, sub ? nullptr : b->d_S, b->d_res,
-                     (int)b->islocal, (int)!b->have_sub);
+                     (int)b->islocal, (int)!b->have_sub, (int)(b->direction == ALN_REV), (int)b->bug_b4);
   ALN_HIP_CHECK(b->ctx, hipGetLastError());
   return ALN_OK;
 }
