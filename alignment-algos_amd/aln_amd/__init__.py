@@ -288,6 +288,30 @@ class Batch:
         _check(lib().aln_batch_get_corner_scores(self.h, _f(s)), self.ctx.h)
         return s
 
+    def enumerate(self, p, kind, number_suboptimal, delta_ratio, flags=None, user_limit=0, max_alignments=None, pairs_capacity=None):
+        """ConstrainedNearOptimal ("cw") / UnconstrainedNearOptimal ("ucw") for pair p -> list of dicts in set order."""
+        Q, T = self.dims(p)
+        noa = AlnNoa(ENUM_CW if kind == "cw" else ENUM_UCW, int(number_suboptimal), float(np.float32(delta_ratio)), int(user_limit))
+        if max_alignments is None:
+            max_alignments = max(int(number_suboptimal), 1) + 2
+        if pairs_capacity is None:
+            pairs_capacity = max_alignments * (min(Q, T) + 3)
+        out = (AlnAlignment * max_alignments)()
+        pairs = np.zeros((pairs_capacity, 2), dtype=np.int32)
+        n = C.c_int32(0)
+        fl = None
+        if flags is not None:
+            fl = np.ascontiguousarray(flags, dtype=np.uint8)
+            assert len(fl) == T
+        _check(lib().aln_batch_enumerate(self.h, p, C.byref(noa), fl.ctypes.data_as(C.POINTER(C.c_uint8)) if fl is not None else None,
+                                         out, max_alignments, _i(pairs), pairs_capacity, C.byref(n)), self.ctx.h)
+        res = []
+        for k in range(n.value):
+            a = out[k]
+            res.append({"score": np.float32(a.score), "identity": np.float32(a.identity), "uid": a.uid,
+                        "pairs": pairs[a.pair_off:a.pair_off + a.n_pairs].copy()})
+        return res
+
     def optimal(self, want_pairs=True, subali=False):
         """-> scores[n], list of pair arrays (list order), status[n]"""
         scores = np.empty(self.n, dtype=np.float32)

@@ -446,10 +446,6 @@ int aln_batch_optimal_subali(aln_batch* b, float* scores, int32_t* n, int32_t* p
   return fetch_paths(b, scores, n, pairs, pair_stride, status, true, true);
 }
 
-int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* noa, const uint8_t* flags, aln_alignment* out,
-                        int32_t max_alignments, int32_t* pairs, int64_t pairs_capacity, int32_t* n_out) {
-  (void)b; (void)pair; (void)noa; (void)flags; (void)out; (void)max_alignments; (void)pairs; (void)pairs_capacity; (void)n_out;
-  return ALN_E_ARG;   // filled in with enumerate.hip
-}
+// aln_batch_enumerate lives in enumerate.hip
 
 }  // extern "C"

@@ -1,0 +1,372 @@
+// enumerate.hip — Waterman-style near-optimal alignment enumeration on the resident DP planes (gfx950).
+//
+// Reference: ConstrainedNearOptimal (cw.h:68-284) and UnconstrainedNearOptimal (ucw.h:64-236): a depth-first
+// branching traceback from the final cell; at a branch node every predecessor (match, then row q0-1 for
+// i = t0-2..1 descending, then column t0-1 for j = q0-2..1 descending) whose forward score plus the reverse
+// score so far minus the gap exceeds the threshold starts a new alignment (the first one continues in the
+// current slot, later ones copy the state before the node); opt_path follows stored pointers until the
+// template's SuboptFlags bit flips.  Discovery order decides the position of every alignment in the set.
+//
+// Device representation: alignments only ever grow by prepend(), so they form a trie — a node is one aligned
+// pair plus a link to the pair after it; an alignment is (head node, score); "copy the alignment" is copying
+// two words.  One wave walks one pair's DFS with an explicit stack of branch frames; the candidate scan of a
+// branch node is done 64 predecessors at a time (ballot keeps the reference's order); fp32 sums are formed in
+// the written order (f + r > thr, (f + r) - g > thr, score = r - g).  The host then sorts (score, index)
+// with the same std::sort / std::partial_sort call the reference uses (alignment.h:922-932) and asks the
+// device to unroll only the surviving alignments.
+#include "aln_device.h"
+
+namespace aln {
+
+constexpr int kFrameWords = 8;   // q0, t0, k0, cursor, curr_head, curr_score, r, (pad) — one active branch() invocation
+
+struct EnumArgs {
+  int kind;             // ALN_ENUM_CW / ALN_ENUM_UCW
+  uint32_t user_limit;
+  float delta_ratio;
+  int first_slot;       // index of the enumerator's seed alignment inside the set (what is already there stays)
+  // pools (for this pair)
+  uint32_t* node_pair; uint32_t* node_next; uint32_t node_cap;
+  uint32_t* head; float* score; uint32_t ali_cap;
+  uint32_t* stack; uint32_t stack_cap;   // frames of kFrameWords words
+  const uint8_t* flags; // T bytes
+  int32_t* out;         // [0] = set size, [1] = nodes used, [2] = status
+};
+
+constexpr uint32_t kNoNode = 0xFFFFFFFFu;
+
+// All mutable pool words are accessed with agent-scope (L2-served) loads/stores: lane 0 writes, every lane reads.
+__device__ __forceinline__ uint32_t ld_u(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_f(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_u(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_f(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(64) void enumerate_kernel(const PairDesc* __restrict__ pairs, int pair, EvalDev proto,
+                                                       const uint8_t* __restrict__ qcodes, const uint8_t* __restrict__ tcodes,
+                                                       const float* __restrict__ tgi, const float* __restrict__ tge,
+                                                       const float* __restrict__ Hbase, const uint32_t* __restrict__ Pbase,
+                                                       const float* __restrict__ Sbase, EnumArgs a) {
+  const PairDesc pd = pairs[pair];
+  EvalDev e = proto;
+  e.Q = pd.Q; e.T = pd.T; e.ld = pd.ld;
+  e.qc = qcodes ? qcodes + pd.q_off : nullptr;
+  e.tc = tcodes ? tcodes + pd.t_off : nullptr;
+  e.tgi = tgi ? tgi + pd.t_off : nullptr;
+  e.tge = tge ? tge + pd.t_off : nullptr;
+  e.S = Sbase ? Sbase + pd.plane_off : nullptr;
+  const float* H = Hbase + pd.plane_off;
+  const uint32_t* P = Pbase + pd.plane_off;
+  const int ld = pd.ld, lane = threadIdx.x;
+  const int Q = pd.Q, T = pd.T;
+  const bool cw = a.kind == ALN_ENUM_CW;
+
+  uint32_t n_as = (uint32_t)a.first_slot + 1;   // as.push_back(SingleAlignment())  cw.h:82 / ucw.h:78
+  uint32_t n_nodes = 0;
+  int status = 0;
+  auto sync_mem = [&]() { __builtin_amdgcn_s_waitcnt(0); };   // vmcnt(0): lane 0's stores are in L2 before anyone reads them
+  if (lane == 0) { st_u(&a.head[a.first_slot], kNoNode); st_f(&a.score[a.first_slot], 0.f); }
+  sync_mem();
+
+  const float top = H[(size_t)(Q - 1) * ld + (T - 1)];
+  float thr = (1.f - a.delta_ratio) * top;       // cw.h:86-88
+  { float alt = top - 0.1f; thr = (alt < thr) ? alt : thr; }
+
+  auto prepend = [&](int k, int q, int t) {     // as[k].prepend(q,t): a new trie node in front of the list
+    if (n_nodes >= a.node_cap) { status = ALN_E_OVERFLOW; return; }
+    if (lane == 0) {
+      a.node_pair[n_nodes] = ((uint32_t)q << 16) | (uint32_t)t;
+      a.node_next[n_nodes] = ld_u(&a.head[k]);
+      st_u(&a.head[k], n_nodes);
+    }
+    ++n_nodes;
+    sync_mem();
+  };
+  auto set_score = [&](int k, float s) { if (lane == 0) st_f(&a.score[k], s); sync_mem(); };
+  auto base_case = [&](int q0, int t0, int k0) {   // cw.h:100-108 / ucw.h:93-101
+    prepend(k0, q0, t0);
+    prepend(k0, 0, 0);
+    float s = ld_f(&a.score[k0]);
+    s += H[(size_t)q0 * ld + t0];
+    set_score(k0, s);
+  };
+  // the pointer-following loop of opt_path (cw.h:242-272 / ucw.h:207-228); returns the cell it stopped at
+  auto walk = [&](int& q0, int& t0, int k0, bool force) {
+    const bool flag = cw ? !a.flags[t0] : false;
+    float sc = ld_f(&a.score[k0]);
+    while (t0 > 1 && q0 > 1 && status == 0) {
+      if (cw && !force && ((a.flags[t0] != 0) == flag)) break;   // the template's SuboptFlags bit flipped: branch point
+      prepend(k0, q0, t0);
+      sc += dev_sim(e, q0, t0);
+      const uint32_t p = P[(size_t)q0 * ld + t0];
+      const int pq = (int)(p >> 16), pt = (int)(p & 0xFFFFu);
+      float g;
+      if (q0 - pq == 1) g = dev_deletion(e, pt, t0);
+      else g = dev_insertion(e, pq, q0, pt, t0);
+      sc -= g;
+      t0 = pt; q0 = pq;
+    }
+    set_score(k0, sc);
+  };
+
+  // Depth-first search with an explicit stack of branch frames.  A pending call is either
+  //   CALL_BRANCH: branch(q,t,k,force)      or      CALL_OPT: opt_path(q,t,k,force)
+  enum { CALL_NONE = 0, CALL_BRANCH = 1, CALL_OPT = 2 };
+  int call = CALL_BRANCH, cq = Q - 1, ct = T - 1, ck = a.first_slot; bool cforce = false;
+  int sp = 0;
+  long guard = 0;
+  while ((call != CALL_NONE || sp > 0) && status == 0) {
+    if (++guard > (1L << 40)) { status = ALN_E_OVERFLOW; break; }
+    if (call == CALL_OPT) {
+      call = CALL_NONE;
+      int q0 = cq, t0 = ct; const int k0 = ck; const bool force = cforce;
+      if (q0 == 1 || t0 == 1) { base_case(q0, t0, k0); continue; }           // cw.h:220-228
+      walk(q0, t0, k0, force);
+      if (cw) { call = CALL_BRANCH; cq = q0; ct = t0; ck = k0; cforce = force; }   // branch(pq,pt,k0,force)  cw.h:276
+      else base_case(q0, t0, k0);                                                    // ucw.h:232-234
+      continue;
+    }
+    if (call == CALL_BRANCH) {
+      call = CALL_NONE;
+      const int q0 = cq, t0 = ct, k0 = ck;
+      if (q0 == 1 || t0 == 1) { base_case(q0, t0, k0); continue; }
+      if (cw && cforce) { call = CALL_OPT; cforce = true; continue; }                          // cw.h:205-209
+      if (n_as > a.user_limit) { call = CALL_OPT; cforce = true; continue; }                   // cw.h:127-140 / ucw.h:110-121
+      if ((uint32_t)sp >= a.stack_cap) { status = ALN_E_OVERFLOW; break; }
+      const uint32_t ch = ld_u(&a.head[k0]);
+      const float cs = ld_f(&a.score[k0]);
+      const float r = cs + dev_sim(e, q0, t0);
+      if (lane == 0) {
+        uint32_t* f = a.stack + (size_t)sp * kFrameWords;
+        st_u(f + 0, (uint32_t)q0); st_u(f + 1, (uint32_t)t0); st_u(f + 2, (uint32_t)k0); st_u(f + 3, 0u);
+        st_u(f + 4, ch); st_u(f + 5, __float_as_uint(cs)); st_u(f + 6, __float_as_uint(r));
+      }
+      sync_mem();
+      ++sp;
+      continue;
+    }
+    // ---- resume the branch frame on top of the stack: scan for the next accepted candidate ----
+    uint32_t* f = a.stack + (size_t)(sp - 1) * kFrameWords;
+    const int q0 = (int)ld_u(f + 0), t0 = (int)ld_u(f + 1), k0 = (int)ld_u(f + 2), cursor = (int)ld_u(f + 3);
+    const uint32_t curr_head = ld_u(f + 4);
+    const float curr_score = __uint_as_float(ld_u(f + 5)), r = __uint_as_float(ld_u(f + 6));
+    const int k = (cursor == 0) ? k0 : (int)n_as;         // k = as.size() after every accepted candidate's subtree
+    const int ndel = t0 - 2, nins = q0 - 2;
+    const int ncand = 1 + ndel + nins;
+    int found = -1; float fg = 0.f; int fq = 0, ft = 0;
+    for (int base = cursor; base < ncand && found < 0; base += 64) {
+      const int idx = base + lane;
+      bool ok = false; float g = 0.f; int pq = 0, pt = 0;
+      if (idx < ncand) {
+        if (idx == 0) {                                     // match, cw.h:151-162
+          pq = q0 - 1; pt = t0 - 1;
+          const float fsc = H[(size_t)pq * ld + pt];
+          ok = fsc + r > thr;
+        } else if (idx <= ndel) {                           // deletions i = t0-2 .. 1, cw.h:166-178
+          pq = q0 - 1; pt = t0 - 1 - idx;
+          const float fsc = H[(size_t)pq * ld + pt];
+          g = dev_deletion(e, pt, t0);
+          ok = fsc + r - g > thr;
+        } else {                                            // insertions j = q0-2 .. 1, cw.h:182-194
+          pq = q0 - 2 - (idx - ndel - 1); pt = t0 - 1;
+          const float fsc = H[(size_t)pq * ld + pt];
+          g = dev_insertion(e, pq, q0, pt, t0);
+          ok = fsc + r - g > thr;
+        }
+      }
+      const unsigned long long m = __ballot(ok);
+      if (m) {
+        const int l = __builtin_ctzll(m);
+        found = base + l;
+        fg = __shfl(g, l); fq = __shfl(pq, l); ft = __shfl(pt, l);
+      }
+    }
+    if (found < 0) {
+      --sp;                                                 // branch() returns
+      if (cursor == 0) {                                    // k == k0: nothing passed, finish along stored pointers
+        call = CALL_OPT; cq = q0; ct = t0; ck = k0; cforce = true;   // cw.h:196-203 / ucw.h:186-191
+      }
+      continue;
+    }
+    if ((uint32_t)k == n_as) {                              // as.push_back(curr)
+      if (n_as >= a.ali_cap) { status = ALN_E_OVERFLOW; break; }
+      if (lane == 0) { st_u(&a.head[n_as], curr_head); st_f(&a.score[n_as], curr_score); }
+      sync_mem();
+      ++n_as;
+    }
+    prepend(k, q0, t0);
+    set_score(k, r - fg);
+    if (lane == 0) st_u(f + 3, (uint32_t)(found + 1));
+    sync_mem();
+    if (cw) { call = CALL_OPT; cq = fq; ct = ft; ck = k; cforce = false; }      // opt_path(cand,k,false)
+    else { call = CALL_BRANCH; cq = fq; ct = ft; ck = k; cforce = false; }      // ucw: branch(cand,k)
+  }
+  if (lane == 0) { a.out[0] = (int32_t)n_as; a.out[1] = (int32_t)n_nodes; a.out[2] = status; }
+}
+
+// unroll selected alignments: one wave per alignment, lane 0 walks the trie (list order = head -> end)
+__global__ __launch_bounds__(64) void enum_unroll_kernel(const uint32_t* __restrict__ node_pair, const uint32_t* __restrict__ node_next,
+                                                         const uint32_t* __restrict__ head, const int32_t* __restrict__ sel, int nsel,
+                                                         int32_t* __restrict__ out_pairs, int32_t* __restrict__ out_n, int stride) {
+  const int s = blockIdx.x;
+  if (s >= nsel || threadIdx.x != 0) return;
+  uint32_t node = head[sel[s]];
+  int n = 0;
+  int32_t* o = out_pairs + (size_t)s * stride * 2;
+  while (node != kNoNode && n < stride) {
+    uint32_t p = node_pair[node];
+    o[2 * n] = (int32_t)(p >> 16); o[2 * n + 1] = (int32_t)(p & 0xFFFFu);
+    ++n;
+    node = node_next[node];
+  }
+  out_n[s] = (node == kNoNode) ? n : -1;
+}
+
+}  // namespace aln
+
+// ---------------------------------------------------------------------------------------------------------
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+using namespace aln;
+
+namespace {
+struct SortKey {
+  float score; int32_t idx;
+  bool operator<(const SortKey& o) const { return score > o.score; }   // alignment.h:104-105 "higher score first"
+};
+}  // namespace
+
+extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* noa, const uint8_t* flags, aln_alignment* out,
+                                   int32_t max_alignments, int32_t* pairs, int64_t pairs_capacity, int32_t* n_out) {
+  if (!b || !noa || !out || !pairs || !n_out || pair < 0 || pair >= b->n_pairs) return ALN_E_ARG;
+  if (!b->have_dp || b->have_sub || b->direction != ALN_FWD) return ALN_E_STATE;
+  if (noa->kind == ALN_ENUM_CW && !flags) return ALN_E_ARG;
+  aln_ctx* ctx = b->ctx;
+  ALN_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const PairDesc& d = b->h_pairs[pair];
+  // the set starts with the pair's Optimal alignment, like the drivers (aa_ali.cpp:83)
+  int rc = launch_traceback(b, false);
+  if (rc) return rc;
+  std::vector<PairResult> res(b->n_pairs);
+  ALN_HIP_CHECK(ctx, hipMemcpyAsync(res.data(), b->d_res, sizeof(PairResult) * b->n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<int32_t> optpath((size_t)b->path_stride * 2);
+  ALN_HIP_CHECK(ctx, hipMemcpyAsync(optpath.data(), b->d_path + (size_t)pair * b->path_stride * 2, optpath.size() * 4,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+  ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (res[pair].status != 0) return res[pair].status;
+
+  const uint32_t user_limit = noa->user_limit ? noa->user_limit : (noa->kind == ALN_ENUM_CW ? 1000000u : 100000u);
+  EnumArgs a = {};
+  a.kind = noa->kind;
+  a.user_limit = user_limit;
+  a.delta_ratio = noa->delta_ratio;
+  a.first_slot = 1;
+  a.ali_cap = user_limit + 65536u;
+  a.node_cap = 48u << 20;
+  if (const char* env = getenv("ALN_ENUM_NODE_CAP")) a.node_cap = (uint32_t)strtoul(env, nullptr, 10);
+  a.stack_cap = (uint32_t)(d.Q + d.T + 8);
+  uint8_t* d_flags = nullptr; int32_t* d_out = nullptr;
+  auto cleanup = [&]() {
+    hipFree(a.node_pair); hipFree(a.node_next); hipFree(a.head); hipFree(a.score); hipFree(a.stack);
+    hipFree(d_flags); hipFree(d_out);
+  };
+#define ETRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup(); return ALN_E_HIP; } } while (0)
+  ETRY(hipMalloc((void**)&a.node_pair, (size_t)a.node_cap * 4));
+  ETRY(hipMalloc((void**)&a.node_next, (size_t)a.node_cap * 4));
+  ETRY(hipMalloc((void**)&a.head, (size_t)a.ali_cap * 4));
+  ETRY(hipMalloc((void**)&a.score, (size_t)a.ali_cap * 4));
+  ETRY(hipMalloc((void**)&a.stack, (size_t)a.stack_cap * kFrameWords * 4));
+  ETRY(hipMalloc((void**)&d_flags, (size_t)d.T));
+  ETRY(hipMalloc((void**)&d_out, 16));
+  if (flags) ETRY(hipMemcpyAsync(d_flags, flags, (size_t)d.T, hipMemcpyHostToDevice, ctx->stream));
+  else ETRY(hipMemsetAsync(d_flags, 1, (size_t)d.T, ctx->stream));
+  a.flags = d_flags;
+  a.out = d_out;
+
+  EvalDev proto = {};
+  proto.model = b->gapdev.model; proto.align_type = b->gapdev.align_type;
+  proto.gi = b->gapdev.gi; proto.ge = b->gapdev.ge;
+  proto.sim_kind = (b->sim_kind == ALN_SIM_SUBMATRIX) ? ALN_SIM_SUBMATRIX : ALN_SIM_MATRIX;
+  proto.tablef = b->d_tablef;
+  const bool sub = b->sim_kind == ALN_SIM_SUBMATRIX;
+  const bool tpos = b->gapdev.model == ALN_GAP_AFFINE_TPOS_MIN;
+  hipLaunchKernelGGL(enumerate_kernel, dim3(1), dim3(64), 0, ctx->stream, b->d_pairs, pair, proto, sub ? b->d_qcodes : nullptr,
+                     sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr, b->d_H, b->d_P,
+                     sub ? nullptr : b->d_S, a);
+  ETRY(hipGetLastError());
+  int32_t hout[4] = {0, 0, 0, 0};
+  ETRY(hipMemcpyAsync(hout, d_out, 12, hipMemcpyDeviceToHost, ctx->stream));
+  ETRY(hipStreamSynchronize(ctx->stream));
+  if (hout[2] != 0) { cleanup(); return hout[2]; }
+  const int n_as = hout[0];
+  std::vector<float> scores(n_as);
+  ETRY(hipMemcpyAsync(scores.data() + 1, a.score + 1, (size_t)(n_as - 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  ETRY(hipStreamSynchronize(ctx->stream));
+  scores[0] = b->islocal ? res[pair].best : res[pair].corner;
+
+  // AlignmentSet::sortSet(number_suboptimal) — alignment.h:922-932, same libstdc++ calls on the same order of keys
+  std::vector<SortKey> keys(n_as);
+  for (int k = 0; k < n_as; ++k) { keys[k].score = scores[k]; keys[k].idx = k; }
+  const int mx = noa->number_suboptimal;
+  if (mx >= n_as) std::sort(keys.begin(), keys.end());
+  else if (mx > 0) { std::partial_sort(keys.begin(), keys.begin() + mx, keys.end()); keys.erase(keys.begin() + mx, keys.end()); }
+  const int n_keep = (int)keys.size();
+  *n_out = n_keep;
+  if (n_keep > max_alignments) { cleanup(); return ALN_E_OVERFLOW; }
+
+  // unroll the survivors on the device
+  std::vector<int32_t> sel;
+  for (int k = 0; k < n_keep; ++k) if (keys[k].idx != 0) sel.push_back(keys[k].idx);
+  const int stride = b->path_stride;
+  std::vector<int32_t> lists((size_t)std::max<size_t>(sel.size(), 1) * stride * 2), lens(std::max<size_t>(sel.size(), 1));
+  if (!sel.empty()) {
+    int32_t *d_sel = nullptr, *d_lists = nullptr, *d_lens = nullptr;
+    hipError_t e1 = hipMalloc((void**)&d_sel, sel.size() * 4);
+    hipError_t e2 = hipMalloc((void**)&d_lists, lists.size() * 4);
+    hipError_t e3 = hipMalloc((void**)&d_lens, sel.size() * 4);
+    bool okk = e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess;
+    if (okk) okk = hipMemcpyAsync(d_sel, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+    if (okk) {
+      hipLaunchKernelGGL(enum_unroll_kernel, dim3((unsigned)sel.size()), dim3(64), 0, ctx->stream, a.node_pair, a.node_next, a.head,
+                         d_sel, (int)sel.size(), d_lists, d_lens, stride);
+      okk = hipGetLastError() == hipSuccess;
+    }
+    if (okk) okk = hipMemcpyAsync(lists.data(), d_lists, lists.size() * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+    if (okk) okk = hipMemcpyAsync(lens.data(), d_lens, sel.size() * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+    if (okk) okk = hipStreamSynchronize(ctx->stream) == hipSuccess;
+    hipFree(d_sel); hipFree(d_lists); hipFree(d_lens);
+    if (!okk) { ctx->last_error = "enumeration unroll failed"; cleanup(); return ALN_E_HIP; }
+  }
+  cleanup();
+#undef ETRY
+  // assemble outputs in set order
+  const std::string qs(b->q_res.data() + d.q_off, d.Q), ts(b->t_res.data() + d.t_off, d.T);
+  int64_t off = 0;
+  size_t si = 0;
+  for (int k = 0; k < n_keep; ++k) {
+    const int idx = keys[k].idx;
+    const int32_t* src; int len;
+    std::vector<int32_t> tmp;
+    if (idx == 0) {
+      len = res[pair].n_path;
+      tmp.resize((size_t)len * 2);
+      for (int i = 0; i < len; ++i) { tmp[2 * i] = optpath[2 * (len - 1 - i)]; tmp[2 * i + 1] = optpath[2 * (len - 1 - i) + 1]; }
+      src = tmp.data();
+    } else {
+      len = lens[si];
+      src = lists.data() + si * (size_t)stride * 2;
+      ++si;
+      if (len < 0) return ALN_E_OVERFLOW;
+    }
+    if (off + len > pairs_capacity) return ALN_E_OVERFLOW;
+    memcpy(pairs + 2 * off, src, (size_t)len * 8);
+    out[k].score = keys[k].score;
+    out[k].uid = (idx == 0) ? -1 : (noa->kind == ALN_ENUM_CW ? 0 : -1);   // cw.h:83 sets uid 0 on its seed; copies inherit it
+    out[k].n_pairs = len;
+    out[k].pair_off = off;
+    out[k].identity = aln_identity(qs.c_str(), d.Q, ts.c_str(), d.T, pairs + 2 * off, len);
+    off += len;
+  }
+  return ALN_OK;
+}

@@ -1,0 +1,106 @@
+"""-m gpu parity tests of near-optimal enumeration (ConstrainedNearOptimal cw.h:68-284, UnconstrainedNearOptimal
+ucw.h:64-236) on the device-resident planes, through the C ABI: set size, discovery/sort order, scores (bit
+patterns), uids, pair lists, gapped strings, identities and FASTA annotations against the golden vectors of
+the real reference and against the oracle on seeded homolog pairs."""
+import numpy as np
+import pytest
+
+import aln_amd
+import goldens
+import gpu_util
+import orc
+from aln_amd.synth import homolog_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _flags(case):
+    return np.array([int(ch) for ch in case["flags"]], dtype=np.uint8) if "flags" in case else np.ones(len(case["t"]) + 2, np.uint8)
+
+
+@pytest.mark.parametrize("prefix", ["known", "enum", "c1", "c4"])
+def test_golden_enumeration(prefix, blosum62):
+    alpha, table = blosum62
+    n_sets = 0
+    for case in goldens.cases(prefix):
+        if case["dir"] != "fwd" or not ("CW" in case["sets"] or "UCW" in case["sets"]):
+            continue
+        b = aln_amd.Batch(gpu_util.ctx(), [case["q"]], [case["t"]])
+        b.dp_submatrix(alpha, table, case["mode"], case["gi"], case["ge"])
+        nsub, delta = case.get("nsub", 10), case.get("delta", 0.3)
+        for key, kind in (("CW", "cw"), ("UCW", "ucw")):
+            if key not in case["sets"]:
+                continue
+            got = b.enumerate(0, kind, nsub, delta, _flags(case))
+            tl, qls, idn = gpu_util.strings_for(case["q"], case["t"], [g["pairs"] for g in got])
+            for g, i in zip(got, idn):
+                assert goldens.f32bits(g["identity"]) == goldens.f32bits(i)
+            ann = [orc.annot(g["score"], g["identity"]) for g in got]
+            goldens.check_set(case, key, got, tl, qls, ann)
+            n_sets += 1
+        b.close()
+    assert n_sets > 0
+
+
+@pytest.mark.parametrize("kind", ["cw", "ucw"])
+def test_enumeration_vs_oracle(kind, blosum62):
+    """Seeded mutated homologs, integer (fast DP kernel) and fractional (exact kernel) gaps, several thresholds, region
+    counts and set limits; one resident batch, every pair enumerated from its own planes."""
+    alpha, table = blosum62
+    rng = np.random.RandomState(17)
+    lens = [9, 24, 57, 64, 90, 130]
+    pairs = [homolog_pair(61000 + n, ln, sub_rate=0.2, indel=3) for n, ln in enumerate(lens)]
+    for mode in (1, 3, 4):
+        for (gi, ge) in ((11, 1), (4.73, 0.34)):
+            b = aln_amd.Batch(gpu_util.ctx(), [p[0] for p in pairs], [p[1] for p in pairs])
+            b.dp_submatrix(alpha, table, mode, gi, ge)
+            for p, (q, t) in enumerate(pairs):
+                T = len(t) + 2
+                flags = orc.make_subopt_regions(T, int(rng.randint(1, 9)))
+                delta = float(rng.choice([0.01, 0.05, 0.1, 0.3]))
+                nsub = int(rng.choice([3, 20, 256]))
+                if kind == "ucw" and len(q) > 60:
+                    delta = min(delta, 0.05)        # keep the unconstrained search small
+                S = orc.sim_submatrix(q, t, alpha, table)
+                gap = orc.Gap(mode, gi, ge)
+                rc, D0, PQ0, PT0 = orc.dp_build(S, gap)
+                rc2, sc, pl = orc.optimal(D0, PQ0, PT0, mode == 3)
+                s = orc.AliSet()
+                s.push(pl, sc)
+                orc.enumerate_noa(kind, D0, PQ0, PT0, S, gap, flags, nsub, delta, s)
+                s.identity(q, t)
+                got = b.enumerate(p, kind, nsub, delta, flags, max_alignments=max(nsub, len(s)) + 2)
+                assert len(got) == len(s), (kind, mode, gi, p, len(got), len(s))
+                for k, g in enumerate(got):
+                    r = s.get(k)
+                    assert np.float32(g["score"]).view(np.uint32) == r["score"].view(np.uint32), (kind, mode, gi, p, k)
+                    assert g["uid"] == r["uid"]
+                    assert np.array_equal(g["pairs"], r["pairs"]), (kind, mode, gi, p, k)
+                    assert np.float32(g["identity"]).view(np.uint32) == r["identity"].view(np.uint32)
+            b.close()
+
+
+def test_enumeration_user_limit_and_overflow(blosum62):
+    """user_limit forces the optimal path once the set is larger (cw.h:127-140); a too-small output buffer is an error."""
+    alpha, table = blosum62
+    q, t = homolog_pair(62001, 80, sub_rate=0.25, indel=3)
+    b = aln_amd.Batch(gpu_util.ctx(), [q], [t])
+    b.dp_submatrix(alpha, table, 1, 11, 1)
+    S = orc.sim_submatrix(q, t, alpha, table)
+    gap = orc.Gap(1, 11, 1)
+    rc, D0, PQ0, PT0 = orc.dp_build(S, gap)
+    rc2, sc, pl = orc.optimal(D0, PQ0, PT0, False)
+    for lim in (5, 40):
+        s = orc.AliSet()
+        s.push(pl, sc)
+        orc.enumerate_noa("ucw", D0, PQ0, PT0, S, gap, None, 100000, 0.2, s, user_limit=lim)
+        got = b.enumerate(0, "ucw", 100000, 0.2, user_limit=lim, max_alignments=len(s) + 2)
+        assert len(got) == len(s)
+        for k, g in enumerate(got):
+            r = s.get(k)
+            assert np.float32(g["score"]).view(np.uint32) == r["score"].view(np.uint32)
+            assert np.array_equal(g["pairs"], r["pairs"])
+    with pytest.raises(aln_amd.AlnError) as ei:
+        b.enumerate(0, "ucw", 100000, 0.2, max_alignments=2)
+    assert ei.value.code == aln_amd.E_OVERFLOW
+    b.close()
