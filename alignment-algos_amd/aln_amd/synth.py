@@ -95,3 +95,17 @@ def homolog_pair(seed, n, sub_rate=0.15, indel=5):
         ins = [AA20[int(r[3 * n + 2 + k]) % 20] for k in range(indel)]
         t = t[:a] + t[a + indel:b] + ins + t[b:]
     return q, "".join(t)[:n].ljust(n, "A")
+
+
+def random_profile(seed, n):
+    """Synthetic HMAP-style profile of n residues + 2 sentinels: per position a 20-vector of U*U
+    normalised to sum 1, an SSE triple normalised to sum 1, a confidence U(0,1).  float32 throughout."""
+    g = MT19937(seed)
+    L = n + 2
+    u = g.draw(L * 40 + L * 3 + L).astype(np.float64) / 4294967296.0
+    a = (u[:L * 20] * u[L * 20:L * 40]).reshape(L, 20) + 1e-3
+    aa = (a / a.sum(axis=1, keepdims=True)).astype(np.float32)
+    s = u[L * 40:L * 43].reshape(L, 3) + 0.05
+    sse = (s / s.sum(axis=1, keepdims=True)).astype(np.float32)
+    conf = u[L * 43:L * 44].astype(np.float32)
+    return {"aa": aa, "sse": sse, "conf": conf}

@@ -163,5 +163,40 @@ def main():
     print("cases", len(cases), "subs", len(subs), "arrays", len(arrays))
 
 
+def gen_profiles():
+    """Profile path: real hmath.h + SimilarityMatrix + DPMatrix + Optimal driven by the plugin evaluator of
+    oracle/ref_profile.cpp (Hmap2Eval itself needs the absent Troll library).  Inputs and outputs in one npz."""
+    from aln_amd.synth import random_profile
+    arrays = {}
+    meta = []
+    # (a 1 x 1 interior has zero variance: hmath.h:53 asserts and the reference aborts)
+    shapes = [(1, 2), (3, 9), (17, 12), (40, 33), (64, 70)]
+    for n, (ql, tl) in enumerate(shapes):
+        qp, tp = random_profile(9700 + n, ql), random_profile(9800 + n, tl)
+        for mode in range(5):
+            for d in (1, 2):
+                if d == 2 and mode not in (1, 3):
+                    continue
+                name = "prof%02d_m%d_d%d" % (n, mode, d)
+                r = refrun.run_profile(qp, tp, mode, 0.5, 1.0, 0.12, 4.73, 0.34, d)
+                for k in ("S", "H", "PQ", "PT", "TGI", "TGE", "PRIM"):
+                    arrays[name + "/" + k] = r[k]
+                m = {"name": name, "inputs": "in%02d" % n, "mode": mode, "dir": d, "alpha": 0.5, "beta": 1.0, "zero_shift": 0.12,
+                     "gi": 4.73, "ge": 0.34}
+                if "OPT" in r["sets"]:
+                    a = r["sets"]["OPT"]["alis"][0]
+                    m["opt"] = {"score": bits(a["score"]), "pairs": a["pairs"].reshape(-1).tolist()}
+                meta.append(m)
+        for side, p in (("q", qp), ("t", tp)):
+            for k in ("aa", "sse", "conf"):
+                arrays["in%02d/%s_%s" % (n, side, k)] = p[k]
+    with open(os.path.join(GOLD, "profile_cases.json"), "w") as f:
+        json.dump({"generator": "oracle/gen_golden.py via oracle/_ref/ref_profile (real hmath.h/DPMatrix/Optimal + plugin evaluator)",
+                   "cases": meta}, f, separators=(",", ":"))
+    np.savez_compressed(os.path.join(GOLD, "profile_cases.npz"), **arrays)
+    print("profile cases", len(meta))
+
+
 if __name__ == "__main__":
     main()
+    gen_profiles()

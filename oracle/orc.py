@@ -221,3 +221,24 @@ def make_subopt_regions(T, regs):
             place = np.float32(place + length)
     flags[T - 1] = 1
     return flags
+
+
+def hmap2_sim(qp, tp, alpha, zero_shift=None):
+    """Hmap2Eval similarity matrix (+ post_process when zero_shift is given)."""
+    Q, T = len(qp["conf"]), len(tp["conf"])
+    S = np.zeros((Q, T), dtype=np.float32)
+    arrs = [np.ascontiguousarray(x, dtype=np.float32) for x in (qp["aa"], qp["sse"], qp["conf"], tp["aa"], tp["sse"], tp["conf"])]
+    lib().orc_sim_hmap2(Q, T, *[_fp(a) for a in arrs], C.c_float(float(np.float32(alpha))), _fp(S))
+    if zero_shift is not None:
+        lib().orc_norm_shift(Q, T, _fp(S), C.c_float(float(np.float32(zero_shift))))
+    return S
+
+
+def hmap2_precalc(tp, gi, ge, beta):
+    T = len(tp["conf"])
+    pc = np.ascontiguousarray(tp["sse"][:, 2], dtype=np.float32)
+    tgi = np.zeros(T, dtype=np.float32)
+    tge = np.zeros(T, dtype=np.float32)
+    lib().orc_hmap2_precalc(T, _fp(pc), C.c_float(float(np.float32(gi))), C.c_float(float(np.float32(ge))),
+                            C.c_float(float(np.float32(beta))), _fp(tgi), _fp(tge))
+    return tgi, tge

@@ -72,3 +72,23 @@ def run_sub(q, t, mode, gi, ge, direction, q1, t1, q2, t2, blosum=BLOSUM62):
     args = [HARNESS, "sub", blosum, str(mode), repr(float(gi)), repr(float(ge)), direction, q, t, str(q1), str(t1), str(q2), str(t2)]
     out = subprocess.run(args, capture_output=True, text=True, timeout=600, check=True).stdout
     return parse(out)
+
+
+def run_profile(qp, tp, mode, alpha, beta, zero_shift, gi, ge, direction=1, timeout=600):
+    """qp/tp: dicts with float32 arrays aa[L,20], sse[L,3], conf[L] (sentinel rows included)."""
+    def seq(p):
+        L = len(p["conf"])
+        lines = [str(L)]
+        for i in range(L):
+            olc = "^" if i == 0 else "$" if i == L - 1 else "A"
+            vals = list(p["aa"][i]) + list(p["sse"][i]) + [p["conf"][i]]
+            lines.append(olc + " " + " ".join("%.9g" % float(v) for v in vals))
+        return "\n".join(lines)
+    text = "%d %.9g %.9g %.9g %.9g %.9g %d\n%s\n%s\n" % (mode, alpha, beta, zero_shift, gi, ge, direction, seq(qp), seq(tp))
+    out = subprocess.run([PROFILE], input=text, capture_output=True, text=True, timeout=timeout, check=True).stdout
+    res = parse(out)
+    for line in out.split("\n"):
+        tag, _, rest = line.partition(" ")
+        if tag in ("TGI", "TGE", "PRIM"):
+            res[tag] = _farr(rest.split())
+    return res
