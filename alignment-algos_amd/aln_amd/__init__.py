@@ -63,7 +63,7 @@ EXPORTS = [
     "aln_batch_create", "aln_batch_destroy", "aln_batch_n_pairs", "aln_batch_device_bytes", "aln_batch_dp",
     "aln_batch_reevaluate", "aln_batch_dp_kernel_name", "aln_batch_dp_sub", "aln_batch_get_cells", "aln_batch_get_sim",
     "aln_batch_get_corner_scores", "aln_batch_optimal", "aln_batch_optimal_subali", "aln_batch_enumerate", "aln_identity",
-    "aln_gapped_length", "aln_gapped_strings", "aln_batch_last_dp_ms", "aln_batch_dp_algorithmic_bytes", "aln_batch_cells",
+    "aln_gapped_length", "aln_gapped_strings", "aln_hmap2_gap_arrays", "aln_batch_last_dp_ms", "aln_batch_dp_algorithmic_bytes", "aln_batch_cells",
 ]
 
 _LIB = None
@@ -116,6 +116,7 @@ def lib():
         L.aln_gapped_strings.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(AlnAlignment), C.c_int32, _ip,
                                          C.c_char_p, C.c_char_p, C.c_int32]
         L.aln_batch_last_dp_ms.argtypes = [C.c_void_p, _fp]
+        L.aln_hmap2_gap_arrays.argtypes = [_fp, C.c_int64, C.c_float, C.c_float, C.c_float, _fp, _fp]
         _LIB = L
     return _LIB
 
@@ -247,6 +248,26 @@ class Batch:
         g = self._gap(align_type, gi, ge)
         bd = np.ascontiguousarray(bounds, dtype=np.int32).reshape(-1)
         _check(lib().aln_batch_dp_sub(self.h, C.byref(s), C.byref(g), direction, _i(bd)), self.ctx.h)
+
+    def dp_hmap2(self, qprof, tprof, align_type, gi, ge, alpha=0.5, beta=1.0, zero_shift=0.12, normalize=True, direction=FWD,
+                 algo=DP_AUTO):
+        """Hmap2Eval on the device.  qprof/tprof: dicts aa[n,20], sse[n,3], conf[n] over the POOLS (sentinels included).
+        pre_calculate (gap arrays from p_coil) runs on the host through aln_hmap2_gap_arrays."""
+        arrs = [np.ascontiguousarray(x, dtype=np.float32) for x in (qprof["aa"], qprof["sse"], qprof["conf"], tprof["aa"], tprof["sse"], tprof["conf"])]
+        nt = len(arrs[5])
+        tgi = np.zeros(nt, dtype=np.float32)
+        tge = np.zeros(nt, dtype=np.float32)
+        _check(lib().aln_hmap2_gap_arrays(_f(arrs[4]), nt, float(np.float32(gi)), float(np.float32(ge)), float(np.float32(beta)), _f(tgi), _f(tge)))
+        s = AlnSim()
+        s.kind = SIM_HMAP2
+        s.q_prof = AlnProfiles(_f(arrs[0]), _f(arrs[1]), _f(arrs[2]))
+        s.t_prof = AlnProfiles(_f(arrs[3]), _f(arrs[4]), _f(arrs[5]))
+        s.alpha = float(np.float32(alpha))
+        s.zero_shift = float(np.float32(zero_shift))
+        s.normalize = int(bool(normalize))
+        g = self._gap(align_type, 0, 0, tgi, tge)
+        _check(lib().aln_batch_dp(self.h, C.byref(s), C.byref(g), direction, algo, 0), self.ctx.h)
+        return tgi, tge
 
     def reevaluate(self):
         _check(lib().aln_batch_reevaluate(self.h), self.ctx.h)

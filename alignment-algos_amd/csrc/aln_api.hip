@@ -292,6 +292,13 @@ int aln_batch_dp(aln_batch* b, const aln_sim* sim, const aln_gap* gap, int32_t d
   if (gap->model == ALN_GAP_AFFINE_TPOS_MIN) { rc = upload_tgaps(b, gap); if (rc) return rc; }
   if (sim->kind == ALN_SIM_SUBMATRIX) { rc = upload_submatrix(b, &sim->sub); if (rc) return rc; }
   else if (sim->kind == ALN_SIM_MATRIX) { rc = upload_simplanes(b, sim, &integral); if (rc) return rc; }
+  else if (sim->kind == ALN_SIM_HMAP2) {
+    // Hmap2Eval: SimilarityMatrix + post_process computed on the device into the resident plane, then a plain plane build
+    ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_pairs, b->h_pairs.data(), sizeof(PairDesc) * b->n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_sim_hmap2(b, sim);
+    if (rc) return rc;
+    b->sim_kind = ALN_SIM_MATRIX;
+  }
   else return ALN_E_ARG;
   b->gap.t_gap_init = nullptr; b->gap.t_gap_extn = nullptr;        // host pointers are not retained
   ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_pairs, b->h_pairs.data(), sizeof(PairDesc) * b->n_pairs, hipMemcpyHostToDevice, ctx->stream));

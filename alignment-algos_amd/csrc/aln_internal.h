@@ -109,5 +109,7 @@ int launch_dp_corner(aln_batch* b);
 int launch_traceback(aln_batch* b, bool subali);
 // dp_exact.hip
 int launch_dp_exact(aln_batch* b);
+// sim_hmap2.hip
+int launch_sim_hmap2(aln_batch* b, const aln_sim* sim);
 
 }  // namespace aln

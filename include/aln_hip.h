@@ -209,6 +209,12 @@ int aln_gapped_strings(const char* qstr, int32_t Q, const char* tstr, int32_t T,
                        const aln_alignment* alis, int32_t n_alis, const int32_t* pairs,
                        char* tline, char* qlines, int32_t stride);
 
+/* Hmap2Eval::pre_calculate (hmap2_eval.cpp:17-25): per template residue gap coefficients
+ * t_gap_init = gap_init * Pi, t_gap_extn = gap_extn * Pi, Pi = exp(beta * (1 - 1.25 * p_coil)), p_coil = sse[3*i+2].
+ * Host arithmetic with the host libm, like the reference; feeds aln_gap.t_gap_init / t_gap_extn. */
+int aln_hmap2_gap_arrays(const float* t_sse, int64_t n, float gap_init, float gap_extn, float beta,
+                         float* t_gap_init, float* t_gap_extn);
+
 /* ---- measurement hooks ---------------------------------------------------------------------- */
 /* Milliseconds the device spent in the DP kernel(s) of the last aln_batch_dp, from HIP events recorded on
  * the ctx stream around those launches; synchronises the stream. */
