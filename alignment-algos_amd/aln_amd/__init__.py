@@ -41,7 +41,7 @@ class AlnProfiles(C.Structure):
 
 class AlnGap(C.Structure):
     _fields_ = [("model", C.c_int32), ("align_type", C.c_int32), ("gap_init", C.c_float), ("gap_extn", C.c_float),
-                ("t_gap_init", _fp), ("t_gap_extn", _fp)]
+                ("t_gap_init", _fp), ("t_gap_extn", _fp), ("dp_local", C.c_int32)]
 
 
 class AlnSim(C.Structure):
@@ -51,7 +51,8 @@ class AlnSim(C.Structure):
 
 
 class AlnNoa(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("number_suboptimal", C.c_int32), ("delta_ratio", C.c_float), ("user_limit", C.c_uint32)]
+    _fields_ = [("kind", C.c_int32), ("number_suboptimal", C.c_int32), ("delta_ratio", C.c_float), ("user_limit", C.c_uint32),
+                ("n_existing", C.c_int32), ("existing_scores", _fp)]
 
 
 class AlnAlignment(C.Structure):
@@ -312,7 +313,7 @@ class Batch:
     def enumerate(self, p, kind, number_suboptimal, delta_ratio, flags=None, user_limit=0, max_alignments=None, pairs_capacity=None):
         """ConstrainedNearOptimal ("cw") / UnconstrainedNearOptimal ("ucw") for pair p -> list of dicts in set order."""
         Q, T = self.dims(p)
-        noa = AlnNoa(ENUM_CW if kind == "cw" else ENUM_UCW, int(number_suboptimal), float(np.float32(delta_ratio)), int(user_limit))
+        noa = AlnNoa(ENUM_CW if kind == "cw" else ENUM_UCW, int(number_suboptimal), float(np.float32(delta_ratio)), int(user_limit), -1, None)
         if max_alignments is None:
             max_alignments = max(int(number_suboptimal), 1) + 2
         if pairs_capacity is None:

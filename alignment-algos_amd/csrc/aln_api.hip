@@ -279,7 +279,7 @@ int aln_batch_dp(aln_batch* b, const aln_sim* sim, const aln_gap* gap, int32_t d
   b->direction = direction;
   b->algo = algo;
   b->bug_b4 = bug_b4;
-  b->islocal = gap->align_type == ALN_LOCAL;                       // dpmatrix.h:155
+  b->islocal = gap->dp_local == 0 ? (gap->align_type == ALN_LOCAL) : (gap->dp_local == 2);   // dpmatrix.h:155
   b->have_sub = false;
   for (PairDesc& d : b->h_pairs) { d.q0 = 0; d.q1 = d.Q - 1; d.t0 = 0; d.t1 = d.T - 1; }
   b->gapdev.model = gap->model;

@@ -245,24 +245,30 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   aln_ctx* ctx = b->ctx;
   ALN_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const PairDesc& d = b->h_pairs[pair];
-  // the set starts with the pair's Optimal alignment, like the drivers (aa_ali.cpp:83)
-  int rc = launch_traceback(b, false);
-  if (rc) return rc;
+  // n_existing < 0: the set starts with the pair's Optimal alignment, like the drivers (aa_ali.cpp:83);
+  // otherwise the caller's set already holds n_existing alignments whose scores take part in sortSet.
+  const bool seed_opt = noa->n_existing < 0;
+  const int n_ex = seed_opt ? 1 : noa->n_existing;
+  if (!seed_opt && n_ex > 0 && !noa->existing_scores) return ALN_E_ARG;
   std::vector<PairResult> res(b->n_pairs);
-  ALN_HIP_CHECK(ctx, hipMemcpyAsync(res.data(), b->d_res, sizeof(PairResult) * b->n_pairs, hipMemcpyDeviceToHost, ctx->stream));
   std::vector<int32_t> optpath((size_t)b->path_stride * 2);
-  ALN_HIP_CHECK(ctx, hipMemcpyAsync(optpath.data(), b->d_path + (size_t)pair * b->path_stride * 2, optpath.size() * 4,
-                                    hipMemcpyDeviceToHost, ctx->stream));
-  ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  if (res[pair].status != 0) return res[pair].status;
+  if (seed_opt) {
+    int rc = launch_traceback(b, false);
+    if (rc) return rc;
+    ALN_HIP_CHECK(ctx, hipMemcpyAsync(res.data(), b->d_res, sizeof(PairResult) * b->n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+    ALN_HIP_CHECK(ctx, hipMemcpyAsync(optpath.data(), b->d_path + (size_t)pair * b->path_stride * 2, optpath.size() * 4,
+                                      hipMemcpyDeviceToHost, ctx->stream));
+    ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (res[pair].status != 0) return res[pair].status;
+  }
 
   const uint32_t user_limit = noa->user_limit ? noa->user_limit : (noa->kind == ALN_ENUM_CW ? 1000000u : 100000u);
   EnumArgs a = {};
   a.kind = noa->kind;
   a.user_limit = user_limit;
   a.delta_ratio = noa->delta_ratio;
-  a.first_slot = 1;
-  a.ali_cap = user_limit + 65536u;
+  a.first_slot = n_ex;
+  a.ali_cap = user_limit + 65536u + (uint32_t)n_ex;
   a.node_cap = 48u << 20;
   if (const char* env = getenv("ALN_ENUM_NODE_CAP")) a.node_cap = (uint32_t)strtoul(env, nullptr, 10);
   a.stack_cap = (uint32_t)(d.Q + d.T + 8);
@@ -301,9 +307,10 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   if (hout[2] != 0) { cleanup(); return hout[2]; }
   const int n_as = hout[0];
   std::vector<float> scores(n_as);
-  ETRY(hipMemcpyAsync(scores.data() + 1, a.score + 1, (size_t)(n_as - 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  ETRY(hipMemcpyAsync(scores.data() + n_ex, a.score + n_ex, (size_t)(n_as - n_ex) * 4, hipMemcpyDeviceToHost, ctx->stream));
   ETRY(hipStreamSynchronize(ctx->stream));
-  scores[0] = b->islocal ? res[pair].best : res[pair].corner;
+  if (seed_opt) scores[0] = b->islocal ? res[pair].best : res[pair].corner;
+  else for (int k = 0; k < n_ex; ++k) scores[k] = noa->existing_scores[k];
 
   // AlignmentSet::sortSet(number_suboptimal) — alignment.h:922-932, same libstdc++ calls on the same order of keys
   std::vector<SortKey> keys(n_as);
@@ -317,7 +324,7 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
 
   // unroll the survivors on the device
   std::vector<int32_t> sel;
-  for (int k = 0; k < n_keep; ++k) if (keys[k].idx != 0) sel.push_back(keys[k].idx);
+  for (int k = 0; k < n_keep; ++k) if (keys[k].idx >= n_ex) sel.push_back(keys[k].idx);
   const int stride = b->path_stride;
   std::vector<int32_t> lists((size_t)std::max<size_t>(sel.size(), 1) * stride * 2), lens(std::max<size_t>(sel.size(), 1));
   if (!sel.empty()) {
@@ -348,7 +355,11 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
     const int idx = keys[k].idx;
     const int32_t* src; int len;
     std::vector<int32_t> tmp;
-    if (idx == 0) {
+    if (idx < n_ex && !seed_opt) {        // one of the caller's own alignments: only its new position is reported
+      out[k].score = keys[k].score; out[k].identity = 0.f; out[k].uid = -1; out[k].n_pairs = -1; out[k].pair_off = idx;
+      continue;
+    }
+    if (idx < n_ex) {
       len = res[pair].n_path;
       tmp.resize((size_t)len * 2);
       for (int i = 0; i < len; ++i) { tmp[2 * i] = optpath[2 * (len - 1 - i)]; tmp[2 * i + 1] = optpath[2 * (len - 1 - i) + 1]; }
@@ -362,7 +373,7 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
     if (off + len > pairs_capacity) return ALN_E_OVERFLOW;
     memcpy(pairs + 2 * off, src, (size_t)len * 8);
     out[k].score = keys[k].score;
-    out[k].uid = (idx == 0) ? -1 : (noa->kind == ALN_ENUM_CW ? 0 : -1);   // cw.h:83 sets uid 0 on its seed; copies inherit it
+    out[k].uid = (idx < n_ex) ? -1 : (noa->kind == ALN_ENUM_CW ? 0 : -1);   // cw.h:83 sets uid 0 on its seed; copies inherit it
     out[k].n_pairs = len;
     out[k].pair_off = off;
     out[k].identity = aln_identity(qs.c_str(), d.Q, ts.c_str(), d.T, pairs + 2 * off, len);

@@ -63,7 +63,7 @@ int aln_gapped_strings(const char* qstr, int32_t Q, const char* tstr, int32_t T,
     s.push_back(tstr[T - 1]);
     memcpy(tline, s.c_str(), s.size() + 1);
   }
-  for (int a = 0; a < n_alis; ++a) {
+  for (int a = 0; a < n_alis && qlines; ++a) {   // qlines == NULL: template line only
     const int32_t* p = pairs + 2 * alis[a].pair_off;
     const int np = alis[a].n_pairs;
     std::string s;

@@ -104,6 +104,8 @@ typedef struct {
   float gap_init, gap_extn;     /* AFFINE_CONST: AliParams::gap_init_penalty / gap_extn_penalty */
   const float* t_gap_init;      /* AFFINE_TPOS_MIN: per residue of the TEMPLATE pool (HMAPElem::gap_init()) */
   const float* t_gap_extn;
+  int32_t dp_local;             /* the DPMatrix constructor's own `type == local` (dpmatrix.h:155) when it differs from the
+                                   evaluator's align_type: 0 = same as align_type, 1 = not local, 2 = local */
 } aln_gap;
 
 /* Similarity source. */
@@ -124,6 +126,10 @@ typedef struct {
   int32_t number_suboptimal;    /* NUM_SUBOPT; sortSet(max) */
   float delta_ratio;            /* DELTA_RATIO */
   uint32_t user_limit;          /* 0 = the reference's hard-coded 1000000 (cw.h:76) / 100000 (ucw.h:72) */
+  int32_t n_existing;           /* < 0: seed the set with the pair's Optimal alignment like the drivers (aa_ali.cpp:83);
+                                   >= 0: the caller's AlignmentSet already holds this many alignments (enumerate() appends) */
+  const float* existing_scores; /* their scores (they take part in sortSet); such entries come back with n_pairs = -1
+                                   and pair_off = their old index */
 } aln_noa;
 
 /* One alignment as the enumerators return it (AlignedPairList, alignment.h:52-113). */
@@ -203,7 +209,8 @@ int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* noa, const ui
 float aln_identity(const char* qstr, int32_t Q, const char* tstr, int32_t T,
                    const int32_t* pairs, int32_t n_pairs);
 /* SequenceGaps (gstrings.h:84-164, gstrings.cpp:17-29): gapped template line and one gapped query line
- * per alignment.  aln_gapped_length() gives the length of every line (without NUL). */
+ * per alignment.  aln_gapped_length() gives the length of every line (without NUL).  qlines may be NULL
+ * (template line only); tline may be NULL. */
 int32_t aln_gapped_length(int32_t T, const aln_alignment* alis, int32_t n_alis, const int32_t* pairs);
 int aln_gapped_strings(const char* qstr, int32_t Q, const char* tstr, int32_t T,
                        const aln_alignment* alis, int32_t n_alis, const int32_t* pairs,

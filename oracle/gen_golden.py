@@ -67,7 +67,7 @@ def main():
     cases = []
     arrays = {}
 
-    def add(name, q, t, mode, gi, ge, direction, ops, full, extra=None):
+    def add(name, q, t, mode, gi, ge, direction, ops, full, extra=None, sets_full=False):
         r = refrun.run_aa(q, t, mode, gi, ge, direction, ops=["dump"] + list(ops))
         c = {"name": name, "q": q, "t": t, "mode": mode, "gi": gi, "ge": ge, "dir": direction}
         if extra:
@@ -81,7 +81,7 @@ def main():
             if full:
                 for k in ("H", "PQ", "PT", "S"):
                     arrays["%s/%s" % (name, k)] = r[k]
-        c["sets"] = {k: set_json(v, None if full else 6) for k, v in r["sets"].items()}
+        c["sets"] = {k: set_json(v, None if (full or sets_full) else 6) for k, v in r["sets"].items()}
         cases.append(c)
 
     # A. known answers of SURVEY.md App. C
@@ -128,6 +128,10 @@ def main():
         for (gi, ge) in ((11, 1), (4.73, 0.34)):
             add("c1_m%d_g%d" % (mode, int(gi)), q, t, mode, gi, ge, "fwd", ["opt", "cw", 256, 0.05, fl], False,
                 {"nsub": 256, "delta": 0.05, "flags": fl})
+    # what the `aaa` driver enumerates without -opt: NOaliParams defaults (200, 0.01), every template flag set
+    for mode, (gi, ge) in ((3, (11, 1)), (4, (4.73, 0.34))):
+        add("aaa_m%d" % mode, q, t, mode, gi, ge, "fwd", ["opt", "cw", 200, 0.01, "1" * 302], False,
+            {"nsub": 200, "delta": 0.01, "flags": "1" * 302}, sets_full=True)
     # a 300-aa homolog pair for long tracebacks + big enumerations (C4-shaped, small)
     q, t = homolog_pair(4242, 300)
     for mode in (3, 1):

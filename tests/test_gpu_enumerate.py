@@ -18,7 +18,7 @@ def _flags(case):
     return np.array([int(ch) for ch in case["flags"]], dtype=np.uint8) if "flags" in case else np.ones(len(case["t"]) + 2, np.uint8)
 
 
-@pytest.mark.parametrize("prefix", ["known", "enum", "c1", "c4"])
+@pytest.mark.parametrize("prefix", ["known", "enum", "c1", "c4", "aaa"])
 def test_golden_enumeration(prefix, blosum62):
     alpha, table = blosum62
     n_sets = 0

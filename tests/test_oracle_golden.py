@@ -20,7 +20,7 @@ def _dp(case, blosum62):
     return S, gap, rc, D, PQ, PT
 
 
-@pytest.mark.parametrize("prefix", ["known", "small", "enum", "mid", "c1", "c4"])
+@pytest.mark.parametrize("prefix", ["known", "small", "enum", "mid", "c1", "c4", "aaa"])
 def test_dp_optimal_enumeration(prefix, blosum62):
     cs = goldens.cases(prefix)
     assert cs
