@@ -98,19 +98,17 @@ def main():
     stream = torch.cuda.current_stream(dev)
     ctx = aln_amd.Context(local_rank, stream.cuda_stream)
     batch = aln_amd.Batch(ctx, qs, ts)          # sequences -> HBM, planes allocated (outside the timed region)
-    scores_dev = torch.empty(args.pairs, dtype=torch.float32, device=dev)
-    gathered = torch.empty(args.pairs * world, dtype=torch.float32, device=dev) if world > 1 else None
-
     # codes + substitution table -> HBM and the first build (the DPMatrix constructors); timed steps then
     # re-run the build on the resident inputs exactly like DPMatrix::reevaluate (dpmatrix.h:213-218)
     batch.dp_submatrix(alphabet, table, mode, gi, ge, aln_amd.FWD, aln_amd.DP_FAST)
 
+    from aln_amd.shard import gather_scores
+
     def step():
         batch.reevaluate()
         sc, _, status = batch.optimal(want_pairs=False)     # find_max + traceback on the device; scores to host
-        if world > 1:
-            scores_dev.copy_(torch.from_numpy(sc))
-            dist.all_gather_into_tensor(gathered, scores_dev)
+        if world > 1:                                       # the one collective of the path: all ranks' scores (RCCL)
+            gather_scores(sc, args.pairs * world, world, rank, device=dev)
         return sc, status
 
     def fence():
