@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <cstring>
 
-#include "aln_internal.h"
+#include "aln_device.h"
 
 using namespace aln;
 
@@ -87,7 +87,7 @@ int aln_batch_create(aln_ctx* ctx, const aln_seqs* queries, const aln_seqs* temp
   b->d_pairs = nullptr; b->d_qcodes = nullptr; b->d_tcodes = nullptr; b->d_H = nullptr; b->d_P = nullptr; b->d_S = nullptr;
   b->d_res = nullptr; b->d_table32 = nullptr; b->d_tablef = nullptr; b->d_tgi = nullptr; b->d_tge = nullptr;
   b->d_path = nullptr; b->d_bounds = nullptr; b->ev0 = nullptr; b->ev1 = nullptr;
-  b->have_dp = false; b->have_sub = false; b->islocal = false; b->alpha_n = 0;
+  b->have_dp = false; b->have_sub = false; b->islocal = false; b->alpha_n = 0; b->ptr_mode = 0;
   b->q_offsets.assign(queries->offsets, queries->offsets + queries->n_seqs + 1);
   b->t_offsets.assign(templates->offsets, templates->offsets + templates->n_seqs + 1);
   b->q_total = b->q_offsets.back();
@@ -248,12 +248,15 @@ int upload_tgaps(aln_batch* b, const aln_gap* gap) {
 int run_dp(aln_batch* b, bool simplane_integral) {
   aln_ctx* ctx = b->ctx;
   const bool sub = b->sim_kind == ALN_SIM_SUBMATRIX;
-  bool fast = false;
-  if (b->algo != ALN_DP_EXACT && !b->have_sub && b->direction == ALN_FWD)
+  bool fast = false, tagged = false;
+  if (b->algo != ALN_DP_EXACT && !b->have_sub && b->direction == ALN_FWD) {
     fast = fast_path_legal(b, sub ? b->h_table.data() : nullptr, b->alpha_n, &b->gap, simplane_integral);
+    tagged = fast && sub && tag_path_legal(b, b->h_table.data(), b->alpha_n, &b->gap) && !getenv("ALN_NO_TAG_KERNEL");
+  }
   if (b->algo == ALN_DP_FAST && !fast) return ALN_E_NOT_INTEGRAL;
+  b->ptr_mode = tagged ? 1 : 0;
   ALN_HIP_CHECK(ctx, hipEventRecord(b->ev0, ctx->stream));
-  int rc = fast ? launch_dp_affine_int(b, !sub) : launch_dp_exact(b);
+  int rc = tagged ? launch_dp_affine_tag(b) : fast ? launch_dp_affine_int(b, !sub) : launch_dp_exact(b);
   if (rc) return rc;
   ALN_HIP_CHECK(ctx, hipEventRecord(b->ev1, ctx->stream));
   rc = launch_dp_corner(b);
@@ -357,10 +360,10 @@ int aln_batch_get_cells(aln_batch* b, int32_t pair, float* score, int32_t* prev_
       size_t s = (size_t)i * d.ld + j, o = (size_t)i * d.T + j;
       if (score) score[o] = h[s];
       if (prev_q || prev_t) {
-        uint32_t v = p[s];
-        int pq = (int)(v >> 16), pt = (int)(v & 0xFFFFu);
-        if (prev_q) prev_q[o] = (pq == 0xFFFF) ? -1 : pq;
-        if (prev_t) prev_t[o] = (pt == 0xFFFF) ? -1 : pt;
+        int pq, pt;
+        decode_ptr(p[s], b->ptr_mode, i, j, pq, pt);
+        if (prev_q) prev_q[o] = pq;
+        if (prev_t) prev_t[o] = pt;
       }
     }
   return ALN_OK;

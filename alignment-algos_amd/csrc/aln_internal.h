@@ -82,6 +82,7 @@ struct aln_batch {
   aln_gap gap;                                 // host copy (pointers not retained beyond dp call)
   aln::GapDev gapdev;
   bool islocal;
+  int32_t ptr_mode;                            // encoding of the P plane words (aln_device.h decode_ptr)
   std::string kernel_name;
   hipEvent_t ev0, ev1;
   std::vector<int32_t> h_bounds;
@@ -103,6 +104,9 @@ namespace aln {
 // dp_affine_int.hip
 int launch_dp_affine_int(aln_batch* b, bool use_simplane);
 bool fast_path_legal(const aln_batch* b, const float* table, int n, const aln_gap* gap, bool simplane_integral);
+// dp_affine_tag.hip
+int launch_dp_affine_tag(aln_batch* b);
+bool tag_path_legal(const aln_batch* b, const float* table, int n, const aln_gap* gap);
 // dp_corner.hip
 int launch_dp_corner(aln_batch* b);
 // traceback.hip

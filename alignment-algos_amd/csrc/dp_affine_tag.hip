@@ -1,0 +1,384 @@
+// dp_affine_tag.hip — tagged-key O(n^2) row-sweep DP for constant affine gaps, integer scores, Q,T <= 2048 (gfx950).
+//
+// Same recurrence, mapping and tie-breaking as dp_affine_int.hip (reference dpmatrix.h:356-689 collapsed per
+// SURVEY.md A.6), rebuilt around what the gfx950 VALU actually issues at full rate.  Measured on MI355X
+// (tools/valu_rate2.hip, 4 waves/SIMD): v_add/v_sub/v_and/v_or/v_ashr/v_mov/v_add_f32/v_mul_f32 issue every
+// ~2.2 cycles; v_max, v_cmp, v_cndmask, every 3-operand VOP3, v_cvt and DPP ops every ~3.8.  The first kernel
+// spent two thirds of its issue slots on v_cmp + v_cndmask pairs that only carried arg-max bookkeeping, and was
+// VALU-issue bound (profiles/r01_a_*).  Here the bookkeeping rides in the low bits of the values:
+//
+//     key = value << 13 | prio << 11 | tag          (value: 19 signed bits, |value| < 2^16 proven on the host)
+//       match      prio 3, tag ignored                      -> predecessor (i-1, j-1)
+//       deletion   prio 2, tag = 2047 - k  (row i-1, col k) -> earliest k wins a tie, as "s > opt_s" demands
+//       insertion  prio 1, tag = 2047 - k  (row k, col j-1)
+//
+// so "first strictly greater candidate in the order match, deletions k^, insertions k^" (dpmatrix.h:453-480) is
+// ONE v_max3_i32 over three keys, a prefix maximum with its first arg-max is ONE v_max_i32 (or one fused
+// v_max_i32_dpp step across lanes), the local-mode clip "s = max(0,s) keeps the match pointer" is one v_max against
+// the key (0, match), and the traceback pointer of a cell is simply the key's low 13 bits (plane mode 1,
+// decoded by aln_device.h::decode_ptr).  Gap constants and the substitution table are pre-shifted by 13, so all
+// additions are plain full-rate adds that leave the tags alone.
+//
+// Per cell: ~18 VALU instructions (was ~63); the kernel is HBM-write bound (8 B per cell: fp32 score + pointer word).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "aln_internal.h"
+
+namespace aln {
+
+namespace tag {
+constexpr int KB = 13;                      // low bits: prio(2) | tag(11)
+constexpr int LOW = (1 << KB) - 1;
+constexpr int TAGMAX = 2047;
+constexpr int P_MATCH = 3 << 11, P_DEL = 2 << 11, P_INS = 1 << 11;
+constexpr int NEGK = -(1 << 30);            // value -2^17: below every real value (|v| < 2^16), headroom for one subtraction
+constexpr int ZKEY = P_MATCH;               // (value 0, match): the clip of local alignments
+constexpr int ORIGIN_DEL = P_DEL | TAGMAX;  // pointer (i-1, 0): cells of row 1 come from the origin by one deletion
+constexpr int ORIGIN_INS = P_INS | TAGMAX;  // pointer (0, j-1): cells of column 1
+}  // namespace tag
+
+struct TagParams {
+  int gi, ge;
+  int free_del, free_ins;
+};
+
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ int tdpp(int old, int src) {
+  return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, BANK_MASK, false);
+}
+// inclusive max-scan over the wave; identity INT_MIN lets every step fuse into one v_max_i32_dpp
+__device__ __forceinline__ int wave_incl_max_key(int v) {
+  const int ident = (int)0x80000000;
+  v = max(v, tdpp<0x111>(ident, v));
+  v = max(v, tdpp<0x112>(ident, v));
+  v = max(v, tdpp<0x114>(ident, v));
+  v = max(v, tdpp<0x118>(ident, v));
+  v = max(v, tdpp<0x142, 0xA>(ident, v));
+  v = max(v, tdpp<0x143, 0xC>(ident, v));
+  return v;
+}
+
+template <int NW, int R, bool LOCAL>
+__global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
+    const PairDesc* __restrict__ pairs, const uint8_t* __restrict__ qcodes, const uint8_t* __restrict__ tcodes,
+    const int32_t* __restrict__ table32, float* __restrict__ Hbase, uint32_t* __restrict__ Pbase,
+    PairResult* __restrict__ res, TagParams prm) {
+  using namespace tag;
+  __shared__ int tab[32 * 32];          // substitution scores << 13
+  __shared__ int xch[2][NW][4];
+  __shared__ int red[NW][2];
+
+  const PairDesc pd = pairs[blockIdx.x];
+  const int Q = pd.Q, T = pd.T, ld = pd.ld;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int W0 = w * 256 * R;
+  const int cb = W0 + 4 * lane;
+  const int gi = prm.gi, ge = prm.ge;
+  float* __restrict__ H = Hbase + pd.plane_off;
+  uint32_t* __restrict__ P = Pbase + pd.plane_off;
+  const uint8_t* __restrict__ qc = qcodes + pd.q_off;
+  const uint8_t* __restrict__ tc = tcodes + pd.t_off;
+
+  for (int k = threadIdx.x; k < 32 * 32; k += 64 * NW) tab[k] = table32[k] * (1 << KB);
+  __syncthreads();
+
+  // ---- static per-column constants -----------------------------------------------------------------
+  int code4[R][4];      // byte offset of the column's residue in a table row
+  int GK[R][4];         // (ge*c) << 13 | P_DEL | (2047 - c): d' + GK = key of A(c) = D + ge*c as a deletion source
+  int EK[R][4];         // (ge*c + gi - ge) << 13: E(c+1) = prefmax - EK
+  bool inrange[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    inrange[r] = (cb + 256 * r) < ld;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const int c = cb + 256 * r + x;
+      int code = kCodeTail;
+      if (c < T) code = tc[c];
+      code4[r][x] = code * 4;
+      GK[r][x] = ((ge * c) * (1 << KB)) | P_DEL | (TAGMAX - (c & TAGMAX));
+      EK[r][x] = (ge * c + gi - ge) * (1 << KB);
+    }
+  }
+  const int CB = W0 + 256 * R;     // first column of the next wave = this wave's boundary target
+  int codeB4 = kCodeTail * 4;
+  if (NW > 1 && CB < T) codeB4 = tc[CB] * 4;
+
+  int dk[R][4];         // D[i-1][c] << 13 (low bits zero)
+  int gmx[R][4];        // running max over k of key(D[k][c] + ge*k, insertion, 2047-k)
+  int cvk[R];           // lane-exclusive prefix key of the row in dk (A-space), per group
+  uint32_t pf[R][4];    // pointer words of the row being finished
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    cvk[r] = NEGK;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { dk[r][x] = 0; gmx[r][x] = NEGK; pf[r][x] = kNullPtr; }
+  }
+  int lmax = 0; uint32_t lpos = 0;
+  int par = 0;
+
+  auto store_row = [&](int i) {
+    const size_t ro = (size_t)i * ld + cb;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (inrange[r]) {
+        const float sc = 1.0f / 8192.0f;       // exact: values are multiples of 2^13
+        float4 hv = make_float4((float)dk[r][0] * sc, (float)dk[r][1] * sc, (float)dk[r][2] * sc, (float)dk[r][3] * sc);
+        uint4 pv = make_uint4(pf[r][0], pf[r][1], pf[r][2], pf[r][3]);
+        *reinterpret_cast<float4*>(H + ro + 256 * r) = hv;
+        *reinterpret_cast<uint4*>(P + ro + 256 * r) = pv;
+      }
+    }
+  };
+  auto tab_at = [&](int qrow, int c4) -> int {
+    return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(tab) + qrow + c4);
+  };
+
+  // Finish the row held in dk[]/pf[] (complete except, for w > 0, the wave's first column which the previous wave
+  // computed and passes as (dB,pB)): prefix-scan preparation for the next row, exchange, local-max tracking, store.
+  auto finish_row = [&](int i, int dB, uint32_t pB) {
+    int sk = NEGK;     // scalar carry: prefix key over this wave's earlier groups
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int tk = NEGK;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        int A = dk[r][x] + GK[r][x];
+        if (r == 0 && x == 0) A = (lane == 0) ? NEGK : A;   // column 0 is never a source; wave firsts are folded below
+        tk = max(tk, A);
+      }
+      const int ik = wave_incl_max_key(tk);
+      const int ek = tdpp<0x138>(NEGK, ik);                 // wave_shr:1 -> exclusive
+      cvk[r] = max(sk, ek);
+      sk = max(sk, __builtin_amdgcn_readlane(ik, 63));
+    }
+    if (NW > 1) {
+      if (lane == 63) { xch[par][w][0] = sk; xch[par][w][1] = dB; xch[par][w][2] = (int)pB; }
+      __syncthreads();
+      if (w > 0) {
+        int fk = NEGK;                                      // prefix over columns 1 .. W0-1
+        for (int v = 0; v < w; ++v) {
+          fk = max(fk, xch[par][v][0]);
+          if (v < w - 1) {
+            const int Cn = (v + 1) * 256 * R;
+            fk = max(fk, xch[par][v][1] + (((ge * Cn) * (1 << KB)) | P_DEL | (TAGMAX - Cn)));
+          }
+        }
+        const int d0 = xch[par][w - 1][1];
+        const uint32_t p0 = (uint32_t)xch[par][w - 1][2];
+        if (lane == 0) { dk[0][0] = d0; pf[0][0] = p0; }
+        const int f2 = max(fk, d0 + (((ge * W0) * (1 << KB)) | P_DEL | (TAGMAX - W0)));
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          int nv = max(f2, cvk[r]);
+          if (r == 0) nv = (lane == 0) ? fk : nv;
+          cvk[r] = nv;
+        }
+      }
+      par ^= 1;
+    }
+    if (LOCAL) {
+      int rm = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) rm = max(rm, dk[r][x]);
+      if (rm > lmax) {                                      // rare: resolve the first column of this lane at the new maximum
+        lmax = rm;
+        int cfirst = 0x7FFFFFFF;
+#pragma unroll
+        for (int r = R - 1; r >= 0; --r)
+#pragma unroll
+          for (int x = 3; x >= 0; --x) cfirst = (dk[r][x] == rm) ? (cb + 256 * r + x) : cfirst;
+        lpos = ((uint32_t)i << 16) | (uint32_t)cfirst;
+      }
+    }
+    store_row(i);
+  };
+
+  // ---- row 0, row 1 -------------------------------------------------------------------------------------
+  store_row(0);   // untouched cells: score 0, null pointer (dpmatrix.cpp:17-25)
+  if (Q >= 3) {
+    // row 1 (dpmatrix.h:409-418 / :579-590): match at (1,1), otherwise one deletion from the origin -> pointer (0,0)
+    const int qrow = (int)qc[1] * 128;
+    auto row1 = [&](int c, int sK, int& dkv, uint32_t& pv) {
+      const int cost = (c >= 2 && !prm.free_del) ? ((gi + ge * (c - 2)) * (1 << KB)) : 0;
+      int v = sK - cost;
+      if (LOCAL) v = max(v, 0);
+      const bool in = (unsigned)(c - 1) < (unsigned)(T - 2);
+      dkv = in ? v : 0;
+      pv = in ? (uint32_t)(c == 1 ? P_MATCH : ORIGIN_DEL) : kNullPtr;
+    };
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) row1(cb + 256 * r + x, tab_at(qrow, code4[r][x]), dk[r][x], pf[r][x]);
+    int dB = 0; uint32_t pB = kNullPtr;
+    if (NW > 1) row1(CB, tab_at(qrow, codeB4), dB, pB);
+    finish_row(1, dB, pB);
+  }
+
+  // ---- interior rows 2 .. Q-2 (dpmatrix.h:447-486 / :607-649) ---------------------------------------------
+  int qcode_next = (Q >= 4) ? (int)qc[2] : 0;
+  for (int i = 2; i <= Q - 2; ++i) {
+    const int qrow = qcode_next * 128;
+    if (i + 1 <= Q - 2) qcode_next = (int)qc[i + 1];
+    const int FK = (gi + ge * (i - 2)) * (1 << KB);                                   // F = gmx - FK
+    const int RK = ((ge * (i - 1)) * (1 << KB)) | P_INS | (TAGMAX - (i - 1));         // key(D[i-1][c] + ge (i-1), insertion from row i-1)
+    const int colK = prm.free_ins ? 0 : FK;                                     // column 1: one insertion from the origin
+
+    int bk[R][4];
+    // cell phase: source column c -> best key of target column c+1 (before the target's similarity)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int pv = cvk[r];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int m = dk[r][x];
+        int A = m + GK[r][x];
+        if (r == 0 && x == 0) A = (cb == 0) ? NEGK : A;     // column 0 is never a source (dpmatrix.h:459 starts at t0+1)
+        const int e = pv - EK[r][x];
+        const int f = gmx[r][x] - FK;
+        bk[r][x] = max(max(m | P_MATCH, e), f);             // v_max3_i32: match > deletion > insertion on equal values
+        pv = max(pv, A);
+      }
+    }
+    // boundary target (first column of the next wave), finished by this wave's lane 63
+    int dB = 0; uint32_t pB = kNullPtr;
+    if (NW > 1) {
+      int kh = bk[R - 1][3] + tab_at(qrow, codeB4);
+      if (LOCAL) kh = max(kh, ZKEY);
+      const bool in = CB <= T - 2;
+      dB = in ? (kh & ~LOW) : 0;
+      pB = in ? (uint32_t)(kh & LOW) : kNullPtr;
+    }
+    // vertical state: row i-1 becomes an insertion source for row i+1
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) gmx[r][x] = max(gmx[r][x], dk[r][x] + RK);
+    // shift one column right, add the target column's similarity, clip, split into score and pointer word
+    int prev_k = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int uk = tdpp<0x138>(0, bk[r][3]);                   // wave_shr:1
+      if (r > 0) uk = (lane == 0) ? prev_k : uk;
+      prev_k = __builtin_amdgcn_readlane(bk[r][3], 63);
+      const bool masked = (r == 0 && W0 == 0) || (W0 + 256 * (r + 1) > T - 1);   // wave-uniform
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int c = cb + 256 * r + x;
+        const int sK = tab_at(qrow, code4[r][x]);
+        int kh = ((x == 0) ? uk : bk[r][x - 1]) + sK;
+        if (LOCAL) kh = max(kh, ZKEY);
+        int dnew = kh & ~LOW;
+        uint32_t pnew = (uint32_t)(kh & LOW);
+        if (masked) {
+          int v1 = sK - colK;                                // column 1 (dpmatrix.h:421-426 / :593-599), pointer (0,0)
+          if (LOCAL) v1 = max(v1, 0);
+          const bool is1 = c == 1;
+          dnew = is1 ? v1 : dnew; pnew = is1 ? (uint32_t)ORIGIN_INS : pnew;
+          const bool in = (unsigned)(c - 1) < (unsigned)(T - 2);
+          dnew = in ? dnew : 0; pnew = in ? pnew : kNullPtr;
+        }
+        dk[r][x] = dnew; pf[r][x] = pnew;
+      }
+    }
+    finish_row(i, dB, pB);
+  }
+
+  // ---- last row: untouched except the corner, which dp_corner_kernel writes --------------------------------
+  if (Q >= 2) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) { dk[r][x] = 0; pf[r][x] = kNullPtr; }
+    store_row(Q - 1);
+  }
+
+  // ---- find_max partial (optimal.h:108-124): value and first row-major position over interior cells ----------
+  if (LOCAL) {
+    int m = lmax;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o));
+    uint32_t p = (lmax == m && m > 0) ? lpos : 0xFFFFFFFFu;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) p = min(p, (uint32_t)__shfl_xor((int)p, o));
+    if (NW > 1) {
+      if (lane == 0) { red[w][0] = m; red[w][1] = (int)p; }
+      __syncthreads();
+      int gm = 0;
+      for (int v = 0; v < NW; ++v) gm = max(gm, red[v][0]);
+      uint32_t gp = 0xFFFFFFFFu;
+      for (int v = 0; v < NW; ++v) if (red[v][0] == gm) gp = min(gp, (uint32_t)red[v][1]);
+      m = gm; p = gp;
+    }
+    if (threadIdx.x == 0) { res[blockIdx.x].part_max = (float)(m >> KB); res[blockIdx.x].part_pos = p; }
+  } else {
+    if (threadIdx.x == 0) { res[blockIdx.x].part_max = 0.f; res[blockIdx.x].part_pos = 0xFFFFFFFFu; }
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+
+// Tagged keys need |every intermediate value| < 2^16 and 11-bit indices.
+bool tag_path_legal(const aln_batch* b, const float* table, int n, const aln_gap* gap) {
+  if (!table || gap->model != ALN_GAP_AFFINE_CONST) return false;
+  if (b->maxQ > 2048 || b->maxT > 2048) return false;
+  const float gi = gap->gap_init, ge = gap->gap_extn;
+  if (!(gi == (float)(int)gi) || !(ge == (float)(int)ge) || gi < 0 || ge < 0) return false;
+  double maxs = 0;
+  for (int k = 0; k < n * n; ++k) {
+    const float v = table[k];
+    if (!(v == (float)(int)v)) return false;
+    if (fabs((double)v) > maxs) maxs = fabs((double)v);
+  }
+  const double bound = (maxs + ge) * ((double)b->maxQ + (double)b->maxT) + gi + maxs;
+  return bound < 65536.0;
+}
+
+template <int NW, int R>
+static int launch_tag_variant(aln_batch* b, const TagParams& prm) {
+  dim3 grid(b->n_pairs), block(64 * NW);
+  hipStream_t st = b->ctx->stream;
+  if (b->islocal)
+    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, true>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
+                       b->d_H, b->d_P, b->d_res, prm);
+  else
+    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, false>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
+                       b->d_H, b->d_P, b->d_res, prm);
+  char nm[96];
+  snprintf(nm, sizeof nm, "dp_affine_tag_kernel<NW=%d,R=%d,%s>", NW, R, b->islocal ? "local" : "global");
+  b->kernel_name = nm;
+  ALN_HIP_CHECK(b->ctx, hipGetLastError());
+  return ALN_OK;
+}
+
+int launch_dp_affine_tag(aln_batch* b) {
+  TagParams prm;
+  prm.gi = (int)b->gap.gap_init;
+  prm.ge = (int)b->gap.gap_extn;
+  prm.free_del = b->gapdev.free_del;
+  prm.free_ins = b->gapdev.free_ins;
+  const int ld = (b->maxT + 3) & ~3;
+  int nw = 0, r = 0;
+  if (const char* e = getenv("ALN_DP_VARIANT")) sscanf(e, "%d,%d", &nw, &r);
+  if (nw == 0) {
+    if (ld <= 256) { nw = 1; r = 1; }
+    else if (ld <= 512) { nw = 2; r = 1; }
+    else if (ld <= 1024) { nw = 4; r = 1; }
+    else { nw = 2; r = 4; }          // measured on config 2: 750 GCUPS vs 741 (4,2) and 673 (8,1)
+  }
+  if (256 * nw * r < ld) return ALN_E_TOO_LONG;
+#define ALN_V(NW_, R_) if (nw == NW_ && r == R_) return launch_tag_variant<NW_, R_>(b, prm)
+  ALN_V(1, 1); ALN_V(1, 2); ALN_V(1, 4); ALN_V(1, 8);
+  ALN_V(2, 1); ALN_V(2, 2); ALN_V(2, 4);
+  ALN_V(4, 1); ALN_V(4, 2);
+  ALN_V(8, 1);
+#undef ALN_V
+  return ALN_E_ARG;
+}
+
+}  // namespace aln

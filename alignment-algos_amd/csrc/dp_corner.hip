@@ -17,7 +17,7 @@ __global__ __launch_bounds__(64) void dp_corner_kernel(const PairDesc* __restric
                                                        const float* __restrict__ tgi, const float* __restrict__ tge,
                                                        float* __restrict__ Hbase, uint32_t* __restrict__ Pbase,
                                                        const float* __restrict__ Sbase, PairResult* __restrict__ res,
-                                                       int islocal, int full_build, int rev, int bug_b4) {
+                                                       int islocal, int full_build, int rev, int bug_b4, int ptr_mode) {
   const PairDesc pd = pairs[blockIdx.x];
   EvalDev e = proto;
   e.Q = pd.Q; e.T = pd.T; e.ld = pd.ld;
@@ -88,7 +88,11 @@ __global__ __launch_bounds__(64) void dp_corner_kernel(const PairDesc* __restric
   }
   if (lane == 0) {
     H[(size_t)fq * ld + ft] = corner;
-    P[(size_t)fq * ld + ft] = cptr;
+    {
+      int cpq, cpt;
+      decode_ptr(cptr, 0, fq, ft, cpq, cpt);
+      P[(size_t)fq * ld + ft] = encode_ptr(ptr_mode, fq, ft, cpq, cpt);   // the final cell speaks the plane's pointer dialect
+    }
     PairResult r = res[blockIdx.x];
     r.corner = corner;
     r.status = 0;
@@ -121,7 +125,7 @@ int launch_dp_corner(aln_batch* b) {
   hipLaunchKernelGGL(dp_corner_kernel, dim3(b->n_pairs), dim3(64), 0, b->ctx->stream, b->d_pairs, proto,
                      sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr,
                      tpos ? b->d_tge : nullptr, b->d_H, b->d_P, sub ? nullptr : b->d_S, b->d_res,
-                     (int)b->islocal, (int)!b->have_sub, (int)(b->direction == ALN_REV), (int)b->bug_b4);
+                     (int)b->islocal, (int)!b->have_sub, (int)(b->direction == ALN_REV), (int)b->bug_b4, (int)b->ptr_mode);
   ALN_HIP_CHECK(b->ctx, hipGetLastError());
   return ALN_OK;
 }

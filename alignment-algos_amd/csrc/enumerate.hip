@@ -30,6 +30,7 @@ struct EnumArgs {
   uint32_t* head; float* score; uint32_t ali_cap;
   uint32_t* stack; uint32_t stack_cap;   // frames of kFrameWords words
   const uint8_t* flags; // T bytes
+  int ptr_mode;         // pointer word encoding of the P plane
   int32_t* out;         // [0] = set size, [1] = nodes used, [2] = status
 };
 
@@ -98,7 +99,8 @@ __global__ __launch_bounds__(64) void enumerate_kernel(const PairDesc* __restric
       prepend(k0, q0, t0);
       sc += dev_sim(e, q0, t0);
       const uint32_t p = P[(size_t)q0 * ld + t0];
-      const int pq = (int)(p >> 16), pt = (int)(p & 0xFFFFu);
+      int pq, pt;
+      decode_ptr(p, a.ptr_mode, q0, t0, pq, pt);
       float g;
       if (q0 - pq == 1) g = dev_deletion(e, pt, t0);
       else g = dev_insertion(e, pq, q0, pt, t0);
@@ -288,6 +290,7 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   if (flags) ETRY(hipMemcpyAsync(d_flags, flags, (size_t)d.T, hipMemcpyHostToDevice, ctx->stream));
   else ETRY(hipMemsetAsync(d_flags, 1, (size_t)d.T, ctx->stream));
   a.flags = d_flags;
+  a.ptr_mode = b->ptr_mode;
   a.out = d_out;
 
   EvalDev proto = {};

@@ -17,6 +17,7 @@ struct TbParams {
   int subali;       // start at the rectangle's far corner and stop at its origin (Optimal_Subali)
   int rev;          // pointers lead towards larger indices (reverse build, Optimal_Rev)
   int stride;       // capacity in pairs of each pair's output list
+  int ptr_mode;     // pointer word encoding of the P plane
 };
 
 __global__ __launch_bounds__(64) void traceback_kernel(const PairDesc* __restrict__ pairs, const float* __restrict__ Hbase,
@@ -53,7 +54,9 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairDesc* __restric
     const float hnext = __shfl_down(h, 1);      // score of the diagonal neighbour (lane+1's cell)
     const bool active = valid && before_stop(cq);   // the while loop would process this cell
     const int nq_ = cq + sg, nt_ = ct + sg;
-    const bool diag = active && nq_ >= 0 && nt_ >= 0 && nq_ < Q && nt_ < T && p == (((uint32_t)nq_ << 16) | (uint32_t)nt_);
+    int dq_, dt_;
+    decode_ptr(p, prm.ptr_mode, cq, ct, dq_, dt_);
+    const bool diag = active && p != kNullPtr && nq_ >= 0 && nt_ >= 0 && nq_ < Q && nt_ < T && dq_ == nq_ && dt_ == nt_;
     bool go = diag && lane < 63;                // lane 63 only supplies hnext for lane 62
     if (prm.islocal) go = go && !(hnext <= 0.f);   // the local loops break BEFORE adding a cell with score <= 0
     const unsigned long long m = __ballot(go);
@@ -67,13 +70,14 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairDesc* __restric
     // state at lane L (the first cell that does not simply continue); L <= 63 because lane 63 never goes
     const int sq = q + sg * L, st = t + sg * L;
     const uint32_t pL = (uint32_t)__shfl((int)p, L);
+    const int jq = __shfl(dq_, L), jt = __shfl(dt_, L);
     const bool diagL = __shfl((int)diag, L) != 0;
     q = sq; t = st; lq = sq; lt = st;
     if (!before_stop(sq)) break;                // natural end of the while loop
     if (diagL && L == 63) continue;             // the run filled the window: reload from (sq,st)
     if (diagL) { lq = sq + sg; lt = st + sg; break; }   // local: neighbour's score <= 0 (optimal.h:98-100)
     // a gap jump (or an untouched cell)
-    const int nq = (int)(pL >> 16), nt = (int)(pL & 0xFFFFu);
+    const int nq = jq, nt = jt;
     if (pL == kNullPtr) { lq = -1; lt = -1; if (!prm.islocal) status = ALN_E_STARTPAIR; break; }
     if (prm.islocal) {
       const float hn = H[(size_t)nq * ld + nt];
@@ -100,6 +104,7 @@ int launch_traceback(aln_batch* b, bool subali) {
   prm.subali = subali ? 1 : 0;
   prm.rev = (b->direction == ALN_REV && !subali) ? 1 : 0;
   prm.stride = b->path_stride;
+  prm.ptr_mode = b->ptr_mode;
   hipLaunchKernelGGL(traceback_kernel, dim3(b->n_pairs), dim3(64), 0, b->ctx->stream, b->d_pairs, b->d_H, b->d_P,
                      b->d_res, b->d_path, prm);
   ALN_HIP_CHECK(b->ctx, hipGetLastError());

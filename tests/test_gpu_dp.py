@@ -198,7 +198,7 @@ def test_random_batch_vs_oracle(mode, blosum62):
     for (gi, ge) in ((11, 1), (3, 0), (0, 2)):
         b = aln_amd.Batch(gpu_util.ctx(), qs, ts)
         b.dp_submatrix(alpha, table, mode, gi, ge, aln_amd.FWD, aln_amd.DP_FAST)
-        assert "dp_affine_int" in b.kernel_name()
+        assert "dp_affine_tag" in b.kernel_name()
         scores, lists, status = b.optimal()
         for p, (q, t) in enumerate(zip(qs, ts)):
             S = orc.sim_submatrix(q, t, alpha, table)
@@ -213,11 +213,15 @@ def test_random_batch_vs_oracle(mode, blosum62):
         b.close()
 
 
+@pytest.mark.parametrize("kernel", ["tag", "int"])
 @pytest.mark.parametrize("variant", ["1,2", "1,8", "2,1", "2,4", "4,1", "4,2", "8,1"])
-def test_kernel_variants_agree(variant, blosum62, monkeypatch):
-    """Every (waves per pair, groups per lane) instantiation of the row-sweep kernel gives the oracle's planes."""
+def test_kernel_variants_agree(variant, kernel, blosum62, monkeypatch):
+    """Every (waves per pair, groups per lane) instantiation of both row-sweep kernels (tagged keys, Q,T <= 2048;
+    plain int32 with explicit arg-max, up to 8192) gives the oracle's planes."""
     alpha, table = blosum62
     monkeypatch.setenv("ALN_DP_VARIANT", variant)
+    if kernel == "int":
+        monkeypatch.setenv("ALN_NO_TAG_KERNEL", "1")
     nw, r = [int(x) for x in variant.split(",")]
     cap = 256 * nw * r - 2
     qs, ts = [], []
@@ -232,7 +236,7 @@ def test_kernel_variants_agree(variant, blosum62, monkeypatch):
     for mode in (3, 1):
         b = aln_amd.Batch(gpu_util.ctx(), qs, ts)
         b.dp_submatrix(alpha, table, mode, 11, 1, aln_amd.FWD, aln_amd.DP_FAST)
-        assert "NW=%d,R=%d" % (nw, r) in b.kernel_name()
+        assert "NW=%d,R=%d" % (nw, r) in b.kernel_name() and ("dp_affine_%s" % kernel) in b.kernel_name()
         for p, (q, t) in enumerate(zip(qs, ts)):
             S = orc.sim_submatrix(q, t, alpha, table)
             rc, D0, PQ0, PT0 = orc.dp_build(S, orc.Gap(mode, 11, 1))
@@ -254,7 +258,7 @@ def test_full_size_properties(blosum62):
     ts = [pr[0][1], pr[1][1], pr[0][0], pr[1][0], pr[0][0]]
     b = aln_amd.Batch(gpu_util.ctx(), qs, ts)
     b.dp_submatrix(alpha, table, aln_amd.LOCAL, 11, 1)
-    assert "dp_affine_int" in b.kernel_name()
+    assert "dp_affine_tag" in b.kernel_name()
     scores, lists, status = b.optimal()
     assert (status == 0).all()
     assert scores[0] == 50.0 and len(lists[0]) == 20
