@@ -132,6 +132,23 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # this box's plain streaming-store rate (torch fill of 8 GiB, HIP events on the same stream): what "HBM-write bound"
+    # can mean on this device today; boxes of the pool differ by ~20 % on it
+    fill_gbs = None
+    try:
+        buf = torch.empty(2 << 30, dtype=torch.float32, device=dev)
+        buf.fill_(1.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            buf.fill_(2.0)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        fill_gbs = 3 * buf.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del buf
+    except Exception:
+        pass
+
     cells_per_step = batch.cells() * world
     value = cells_per_step * args.steps / elapsed / 1e9
     dp_ms = float(np.mean(kernel_ms))
@@ -155,7 +172,8 @@ def main():
                    "kernel": batch.kernel_name()},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel_ms": round(dp_ms, 3), "algorithmic_bytes": algo_bytes},
+                     "kernel_ms": round(dp_ms, 3), "algorithmic_bytes": algo_bytes,
+                     "measured_fill_GBs_this_box": round(fill_gbs, 1) if fill_gbs else None},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(qs[0], ts[0], mode, gi, ge)
