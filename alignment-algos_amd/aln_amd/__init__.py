@@ -64,7 +64,7 @@ EXPORTS = [
     "aln_batch_create", "aln_batch_destroy", "aln_batch_n_pairs", "aln_batch_device_bytes", "aln_batch_dp",
     "aln_batch_reevaluate", "aln_batch_dp_kernel_name", "aln_batch_dp_sub", "aln_batch_get_cells", "aln_batch_get_sim",
     "aln_batch_get_corner_scores", "aln_batch_optimal", "aln_batch_optimal_subali", "aln_batch_enumerate", "aln_identity",
-    "aln_gapped_length", "aln_gapped_strings", "aln_hmap2_gap_arrays", "aln_batch_last_dp_ms", "aln_batch_dp_algorithmic_bytes", "aln_batch_cells",
+    "aln_gapped_length", "aln_gapped_strings", "aln_hmap2_gap_arrays", "aln_score_all_vs_all", "aln_batch_last_dp_ms", "aln_batch_dp_algorithmic_bytes", "aln_batch_cells",
 ]
 
 _LIB = None
@@ -117,6 +117,8 @@ def lib():
         L.aln_gapped_strings.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(AlnAlignment), C.c_int32, _ip,
                                          C.c_char_p, C.c_char_p, C.c_int32]
         L.aln_batch_last_dp_ms.argtypes = [C.c_void_p, _fp]
+        L.aln_score_all_vs_all.argtypes = [C.c_void_p, C.POINTER(AlnSeqs), C.POINTER(AlnSeqs), C.POINTER(AlnSubmatrix), C.POINTER(AlnGap),
+                                           C.c_int32, C.c_int32, _fp]
         L.aln_hmap2_gap_arrays.argtypes = [_fp, C.c_int64, C.c_float, C.c_float, C.c_float, _fp, _fp]
         _LIB = L
     return _LIB
@@ -167,6 +169,25 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+def score_all_vs_all(ctx, queries, templates, alphabet, table, gi, ge, q_begin=0, q_end=None):
+    """Optimal local scores of queries[q_begin:q_end] against every template, no planes (aln_score_all_vs_all)."""
+    qpool = queries if isinstance(queries, SeqPool) else SeqPool(queries)
+    tpool = templates if isinstance(templates, SeqPool) else SeqPool(templates)
+    if q_end is None:
+        q_end = len(qpool.seqs)
+    tab = np.ascontiguousarray(table, dtype=np.float32)
+    ab = alphabet.encode()
+    sub = AlnSubmatrix(len(alphabet), ab, _f(tab))
+    g = AlnGap()
+    g.model = GAP_AFFINE_CONST
+    g.align_type = LOCAL
+    g.gap_init = float(np.float32(gi))
+    g.gap_extn = float(np.float32(ge))
+    out = np.empty((q_end - q_begin, len(tpool.seqs)), dtype=np.float32)
+    _check(lib().aln_score_all_vs_all(ctx.h, C.byref(qpool.c), C.byref(tpool.c), C.byref(sub), C.byref(g), q_begin, q_end, _f(out)), ctx.h)
+    return out
 
 
 class Batch:

@@ -1,0 +1,254 @@
+// score_only.hip — all-vs-all local alignment SCORES, no planes (BASELINE config 5) (gfx950).
+//
+// The score Optimal reports for a local build is find_max over the matrix (optimal.h:90-93, :108-124): the
+// maximum cell of the DPMatrix::build_forw_local_dpm_nonlinear_gaps recurrence (dpmatrix.h:538-689).  When nobody
+// needs cells or pointers nothing per-cell has to touch HBM: one wave per (query, template) pair sweeps the rows
+// with the whole state in VGPRs — the same collapsed recurrence as dp_affine_tag.hip, without tags:
+//   E(j) by a DPP max-plus prefix scan of A(k) = D[i-1][k] + ge k, F by a per-column running max of D[k][c] + ge k,
+//   best = max3(match, E, F) + S, clipped at 0, running maximum per lane.
+// Algorithmic bytes per pair: |q| + |t| residue bytes in, 4 bytes out (~0 B/cell) — the kernel is
+// bound by VALU issue (about 6 half-rate + 8 full-rate instructions per cell), not by HBM.
+// Grid: x = template index, y = query index inside the caller's row block; templates are replicated on every GPU,
+// query rows are what ranks shard.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "aln_internal.h"
+
+namespace aln {
+
+constexpr int kNegS = -(1 << 28);
+
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ int sdpp(int old, int src) {
+  return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, BANK_MASK, false);
+}
+__device__ __forceinline__ int wave_incl_max_s(int v) {
+  const int ident = (int)0x80000000;
+  v = max(v, sdpp<0x111>(ident, v));
+  v = max(v, sdpp<0x112>(ident, v));
+  v = max(v, sdpp<0x114>(ident, v));
+  v = max(v, sdpp<0x118>(ident, v));
+  v = max(v, sdpp<0x142, 0xA>(ident, v));
+  v = max(v, sdpp<0x143, 0xC>(ident, v));
+  return v;
+}
+
+struct ScoreArgs {
+  const uint8_t* qcodes; const int64_t* qoff;   // query pool, offsets (n_q + 1)
+  const uint8_t* tcodes; const int64_t* toff;   // template pool
+  const int32_t* table32;                       // 32 x 32
+  float* scores;                                // rows x n_t
+  int q_begin, n_t;
+  int gi, ge;
+};
+
+template <int R>
+__global__ __launch_bounds__(64) void score_local_kernel(ScoreArgs a) {
+  __shared__ int tab[32 * 32];
+  const int lane = threadIdx.x;
+  for (int k = lane; k < 32 * 32; k += 64) tab[k] = a.table32[k];
+  __syncthreads();
+  const int ti = blockIdx.x, qi = a.q_begin + blockIdx.y;
+  const uint8_t* __restrict__ qc = a.qcodes + a.qoff[qi];
+  const uint8_t* __restrict__ tc = a.tcodes + a.toff[ti];
+  const int Q = (int)(a.qoff[qi + 1] - a.qoff[qi]), T = (int)(a.toff[ti + 1] - a.toff[ti]);
+  const int gi = a.gi, ge = a.ge;
+  const int cb = 4 * lane;
+  const int gime = gi - ge;
+
+  int code4[R][4], gec[R][4];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const int c = cb + 256 * r + x;
+      int code = kCodeTail;
+      if (c < T) code = tc[c];
+      code4[r][x] = code * 4;
+      gec[r][x] = ge * c;
+    }
+  int d[R][4], gmx[R][4], cv[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    cv[r] = kNegS;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { d[r][x] = 0; gmx[r][x] = kNegS; }
+  }
+  int lmax = 0;
+  auto tab_at = [&](int qrow, int c4) -> int {
+    return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(tab) + qrow + c4);
+  };
+  // prefix-scan preparation on the row held in d[] + running maximum
+  auto finish_row = [&]() {
+    int sk = kNegS;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int tk = kNegS;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        int A = d[r][x] + gec[r][x];
+        if (r == 0 && x == 0) A = (lane == 0) ? kNegS : A;   // column 0 is never a source
+        tk = max(tk, A);
+        lmax = max(lmax, d[r][x]);
+      }
+      const int ik = wave_incl_max_s(tk);
+      const int ek = sdpp<0x138>(kNegS, ik);
+      cv[r] = max(sk, ek);
+      sk = max(sk, __builtin_amdgcn_readlane(ik, 63));
+    }
+  };
+  if (Q >= 3) {
+    // row 1 (dpmatrix.h:579-590): local mode -> end gaps are free: clip(S[1][c])
+    const int qrow = (int)qc[1] * 128;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int c = cb + 256 * r + x;
+        const int h = max(tab_at(qrow, code4[r][x]), 0);
+        d[r][x] = ((unsigned)(c - 1) < (unsigned)(T - 2)) ? h : 0;
+      }
+    finish_row();
+  }
+  int qcode_next = (Q >= 4) ? (int)qc[2] : 0;
+  for (int i = 2; i <= Q - 2; ++i) {                        // dpmatrix.h:607-649
+    const int qrow = qcode_next * 128;
+    if (i + 1 <= Q - 2) qcode_next = (int)qc[i + 1];
+    const int roff = gi + ge * (i - 2);
+    const int rowB = ge * (i - 1);
+    int bk[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int pv = cv[r];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int m = d[r][x];
+        int A = m + gec[r][x];
+        if (r == 0 && x == 0) A = (lane == 0) ? kNegS : A;
+        const int e = pv - gec[r][x] - gime;
+        const int f = gmx[r][x] - roff;
+        bk[r][x] = max(max(m, e), f);
+        pv = max(pv, A);
+        gmx[r][x] = max(gmx[r][x], m + rowB);
+      }
+    }
+    int prev_k = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int uk = sdpp<0x138>(0, bk[r][3]);
+      if (r > 0) uk = (lane == 0) ? prev_k : uk;
+      prev_k = __builtin_amdgcn_readlane(bk[r][3], 63);
+      const bool masked = (r == 0) || (256 * (r + 1) > T - 1);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int c = cb + 256 * r + x;
+        const int s = tab_at(qrow, code4[r][x]);
+        int h = max(((x == 0) ? uk : bk[r][x - 1]) + s, 0);
+        if (masked) {
+          const int h1 = max(s, 0);                          // column 1: free insertion from the origin (:593-599)
+          h = (c == 1) ? h1 : h;
+          h = ((unsigned)(c - 1) < (unsigned)(T - 2)) ? h : 0;
+        }
+        d[r][x] = h;
+      }
+    }
+    finish_row();
+  }
+  int m = lmax;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o));
+  if (lane == 0) a.scores[(size_t)blockIdx.y * a.n_t + ti] = (float)m;
+}
+
+}  // namespace aln
+
+using namespace aln;
+
+// Optimal local scores of queries[q_begin .. q_end) against every template: scores[(q - q_begin) * n_t + t].
+// Replaces (q_end - q_begin) x n_t constructions of DPMatrix(q, t, AASubstitutionEval, fwd, local) + Optimal(local).
+extern "C" int aln_score_all_vs_all(aln_ctx* ctx, const aln_seqs* queries, const aln_seqs* templates, const aln_submatrix* sub,
+                                    const aln_gap* gap, int32_t q_begin, int32_t q_end, float* scores) {
+  if (!ctx || !queries || !templates || !sub || !gap || !scores) return ALN_E_ARG;
+  if (q_begin < 0 || q_end > queries->n_seqs || q_begin > q_end) return ALN_E_ARG;
+  if (gap->model != ALN_GAP_AFFINE_CONST || gap->align_type != ALN_LOCAL) return ALN_E_ARG;   // round 1: local scores only
+  if (!sub->alphabet || !sub->table || sub->n < 1 || sub->n > 30) return ALN_E_ARG;
+  ALN_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const float gi = gap->gap_init, ge = gap->gap_extn;
+  if (!(gi == (float)(int)gi) || !(ge == (float)(int)ge) || gi < 0 || ge < 0) return ALN_E_NOT_INTEGRAL;
+  int idx[256];
+  for (int i = 0; i < 256; ++i) idx[i] = -1;
+  for (int i = 0; i < sub->n; ++i) idx[(unsigned char)sub->alphabet[i]] = i;
+  int32_t ti[32 * 32];
+  double maxs = 0;
+  for (int i = 0; i < 32 * 32; ++i) ti[i] = 0;
+  for (int i = 0; i < sub->n; ++i)
+    for (int j = 0; j < sub->n; ++j) {
+      float v = sub->table[i * sub->n + j];
+      if (!(v == (float)(int)v)) return ALN_E_NOT_INTEGRAL;
+      ti[i * 32 + j] = (int32_t)v;
+      maxs = std::max(maxs, fabs((double)v));
+    }
+  auto encode = [&](const aln_seqs* s, std::vector<uint8_t>& codes, int& maxlen) -> int {
+    const int64_t total = s->offsets[s->n_seqs];
+    codes.resize((size_t)total);
+    for (int64_t k = 0; k < total; ++k) {
+      unsigned char ch = (unsigned char)s->residues[k];
+      int c = (ch == '^') ? kCodeHead : (ch == '$') ? kCodeTail : idx[ch];
+      if (c < 0) return ALN_E_RESIDUE;
+      codes[(size_t)k] = (uint8_t)c;
+    }
+    maxlen = 0;
+    for (int i = 0; i < s->n_seqs; ++i) {
+      int64_t len = s->offsets[i + 1] - s->offsets[i];
+      if (len < 2) return ALN_E_ARG;
+      maxlen = std::max<int>(maxlen, (int)len);
+    }
+    return ALN_OK;
+  };
+  std::vector<uint8_t> qc, tc;
+  int maxQ = 0, maxT = 0, rc;
+  if ((rc = encode(queries, qc, maxQ)) != ALN_OK) return rc;
+  if ((rc = encode(templates, tc, maxT)) != ALN_OK) return rc;
+  if (maxT > 2048 || maxQ > kMaxLen) return ALN_E_TOO_LONG;
+  if ((maxs + ge) * ((double)maxQ + maxT) + gi + maxs >= 8388608.0) return ALN_E_NOT_INTEGRAL;
+  const int rows = q_end - q_begin, n_t = templates->n_seqs;
+  if (rows == 0 || n_t == 0) return ALN_OK;
+
+  ScoreArgs a = {};
+  uint8_t *dq = nullptr, *dt = nullptr; int64_t *dqo = nullptr, *dto = nullptr; int32_t* dtab = nullptr; float* dsc = nullptr;
+  auto cleanup = [&]() { hipFree(dq); hipFree(dt); hipFree(dqo); hipFree(dto); hipFree(dtab); hipFree(dsc); };
+#define STRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup(); return ALN_E_HIP; } } while (0)
+  STRY(hipMalloc((void**)&dq, qc.size())); STRY(hipMalloc((void**)&dt, tc.size()));
+  STRY(hipMalloc((void**)&dqo, (size_t)(queries->n_seqs + 1) * 8)); STRY(hipMalloc((void**)&dto, (size_t)(n_t + 1) * 8));
+  STRY(hipMalloc((void**)&dtab, sizeof ti)); STRY(hipMalloc((void**)&dsc, (size_t)rows * n_t * 4));
+  STRY(hipMemcpyAsync(dq, qc.data(), qc.size(), hipMemcpyHostToDevice, ctx->stream));
+  STRY(hipMemcpyAsync(dt, tc.data(), tc.size(), hipMemcpyHostToDevice, ctx->stream));
+  STRY(hipMemcpyAsync(dqo, queries->offsets, (size_t)(queries->n_seqs + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  STRY(hipMemcpyAsync(dto, templates->offsets, (size_t)(n_t + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  STRY(hipMemcpyAsync(dtab, ti, sizeof ti, hipMemcpyHostToDevice, ctx->stream));
+  a.qcodes = dq; a.qoff = dqo; a.tcodes = dt; a.toff = dto; a.table32 = dtab; a.scores = dsc;
+  a.q_begin = q_begin; a.n_t = n_t; a.gi = (int)gi; a.ge = (int)ge;
+  const int ld = (maxT + 3) & ~3;
+  const dim3 block(64);
+  // blockIdx.y is limited to 65535: walk the query rows in slabs
+  for (int r0 = 0; r0 < rows; r0 += 32768) {
+    const int nr = std::min(32768, rows - r0);
+    ScoreArgs s = a;
+    s.q_begin = q_begin + r0;
+    s.scores = dsc + (size_t)r0 * n_t;
+    const dim3 grid(n_t, nr);
+    if (ld <= 256) hipLaunchKernelGGL(score_local_kernel<1>, grid, block, 0, ctx->stream, s);
+    else if (ld <= 512) hipLaunchKernelGGL(score_local_kernel<2>, grid, block, 0, ctx->stream, s);
+    else if (ld <= 1024) hipLaunchKernelGGL(score_local_kernel<4>, grid, block, 0, ctx->stream, s);
+    else hipLaunchKernelGGL(score_local_kernel<8>, grid, block, 0, ctx->stream, s);
+    STRY(hipGetLastError());
+  }
+  STRY(hipMemcpyAsync(scores, dsc, (size_t)rows * n_t * 4, hipMemcpyDeviceToHost, ctx->stream));
+  STRY(hipStreamSynchronize(ctx->stream));
+#undef STRY
+  cleanup();
+  return ALN_OK;
+}

@@ -204,6 +204,15 @@ int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* noa, const ui
                         aln_alignment* out, int32_t max_alignments,
                         int32_t* pairs, int64_t pairs_capacity, int32_t* n_out);
 
+/* ---- all-vs-all scoring without planes (BASELINE config 5) ------------------------------------ */
+/* The score Optimal(local) reports (find_max, optimal.h:90-93,108-124) for queries[q_begin..q_end) against EVERY
+ * template: scores[(q - q_begin) * templates->n_seqs + t].  Replaces that many DPMatrix(q, t, AASubstitutionEval, fwd,
+ * local) + Optimal constructions; nothing per cell is written to HBM.  A rank of a multi-GPU job calls it with its own
+ * block of query rows.  Round 1: ALN_GAP_AFFINE_CONST with integer values, align_type ALN_LOCAL,
+ * templates up to 2046 residues; anything else -> ALN_E_ARG / ALN_E_NOT_INTEGRAL / ALN_E_TOO_LONG. */
+int aln_score_all_vs_all(aln_ctx* ctx, const aln_seqs* queries, const aln_seqs* templates, const aln_submatrix* sub,
+                         const aln_gap* gap, int32_t q_begin, int32_t q_end, float* scores);
+
 /* ---- host-side helpers with no device work (alignment.h / gstrings.h) -------------------- */
 /* AlignedPairList::calcIdentity (alignment.h:856-865). qstr/tstr include sentinels. */
 float aln_identity(const char* qstr, int32_t Q, const char* tstr, int32_t T,

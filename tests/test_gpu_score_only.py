@@ -1,0 +1,61 @@
+"""-m gpu: all-vs-all score-only path (BASELINE config 5 shape): aln_score_all_vs_all against (a) the resident-plane
+path's Optimal(local) scores for every pair and (b) the oracle on a sample; ragged lengths around every kernel
+variant boundary (256/512/1024 columns), row-block calls as a rank of a multi-GPU job would issue them."""
+import numpy as np
+import pytest
+
+import aln_amd
+import gpu_util
+import orc
+from aln_amd.synth import MT19937, homolog_pair, residues
+
+pytestmark = pytest.mark.gpu
+
+
+def make_set(seed, lens):
+    out = []
+    for n, ln in enumerate(lens):
+        g = MT19937(seed + n)
+        out.append(residues(g, ln))
+    return out
+
+
+@pytest.mark.parametrize("tmax", [120, 254, 255, 500, 1022, 1500])
+def test_scores_equal_plane_path_and_oracle(tmax, blosum62):
+    alpha, table = blosum62
+    rng = np.random.RandomState(tmax)
+    qlens = [1, 7, 64, 200, 333] + [int(rng.randint(2, 400)) for _ in range(4)]
+    tlens = [tmax, tmax - 1, 1, 5, max(tmax // 2, 2)] + [int(rng.randint(2, tmax)) for _ in range(4)]
+    qs, ts = make_set(81000 + tmax, qlens), make_set(82000 + tmax, tlens)
+    # plant homologs so that some scores are large
+    h1, h2 = homolog_pair(83000 + tmax, min(tmax, 200))
+    qs[3], ts[4] = h1, h2[:tlens[4]] if tlens[4] < len(h2) else h2
+    ctx = gpu_util.ctx()
+    got = aln_amd.score_all_vs_all(ctx, qs, ts, alpha, table, 11, 1)
+    assert got.shape == (len(qs), len(ts))
+    # (a) every pair through the plane path (tagged DP kernel + find_max)
+    qi, ti = np.meshgrid(np.arange(len(qs)), np.arange(len(ts)), indexing="ij")
+    b = aln_amd.Batch(ctx, qs, ts, qi.reshape(-1), ti.reshape(-1))
+    b.dp_submatrix(alpha, table, aln_amd.LOCAL, 11, 1)
+    scores, _, status = b.optimal(want_pairs=False)
+    b.close()
+    assert np.array_equal(got.reshape(-1).view(np.uint32), scores.view(np.uint32))
+    # (b) the oracle on a sample
+    for (i, j) in [(0, 0), (3, 4), (4, 0), (8, 8), (2, 1)]:
+        S = orc.sim_submatrix(qs[i], ts[j], alpha, table)
+        rc, D, PQ, PT = orc.dp_build(S, orc.Gap(orc.LOCAL, 11, 1))
+        assert got[i, j] == orc.optimal(D, PQ, PT, True)[1]
+    # row blocks (what one rank of a sharded job computes)
+    blk = aln_amd.score_all_vs_all(ctx, qs, ts, alpha, table, 11, 1, 2, 7)
+    assert np.array_equal(blk, got[2:7])
+
+
+def test_score_only_rejects_what_it_cannot_do(blosum62):
+    alpha, table = blosum62
+    ctx = gpu_util.ctx()
+    with pytest.raises(aln_amd.AlnError) as ei:
+        aln_amd.score_all_vs_all(ctx, ["ACD"], ["ACD"], alpha, table, 4.73, 0.34)
+    assert ei.value.code == aln_amd.E_NOT_INTEGRAL
+    with pytest.raises(aln_amd.AlnError) as ei:
+        aln_amd.score_all_vs_all(ctx, ["ACJ"], ["ACD"], alpha, table, 11, 1)
+    assert ei.value.code == aln_amd.E_RESIDUE
