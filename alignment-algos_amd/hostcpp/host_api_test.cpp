@@ -1,0 +1,90 @@
+// host_api_test.cpp — exercises the C++ host mirror end to end on the GPU (used by tests/test_gpu_hostcpp.py):
+//   profile <mode> <q.hmap> <t.hmap>      DPMatrix<HMAPSequence,SMAPSequence,Hmap2Eval> + Optimal -> score bits, pairs, probes
+//   aa <mode> <gi> <ge> <dir> <q> <t> <blosum>   DPMatrix<AASequence,...> fwd/rev + Optimal/Optimal_Rev + ucw, cells via getCell
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include "aa_seq.h"
+#include "aasubalib.h"
+#include "cw.h"
+#include "dpmatrix.h"
+#include "hmap2_eval.h"
+#include "optimal.h"
+#include "optimal_rev.h"
+#include "ucw.h"
+
+static unsigned fbits(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+
+template <class Set>
+static void dump(const char* tag, Set& as) {
+  printf("%s %d\n", tag, (int)as.size());
+  for (size_t a = 0; a < as.size(); ++a) {
+    printf("ALI %08x %08x %d %d", fbits(as[a].score), fbits(as[a].identity), as[a].uid, (int)as[a].size());
+    for (typename Set::value_type::const_iterator it = as[a].begin(); it != as[a].end(); ++it) printf(" %d %d", it->first, it->second);
+    printf("\n");
+  }
+}
+
+int main(int argc, char** argv) {
+  try {
+    std::string cmd = argv[1];
+    if (cmd == "profile") {
+      Gn2Params p;
+      p.align_type = (align_t)atoi(argv[2]);
+      HMAPSequence q(argv[3]);
+      SMAPSequence t(argv[4]);
+      Hmap2Eval ev(p);
+      DPMatrix<HMAPSequence, SMAPSequence, Hmap2Eval> dpm(q, t, ev, fwd, p.align_type);
+      Optimal<HMAPSequence, SMAPSequence, Hmap2Eval> opt(p.align_type);
+      AlignmentSet<HMAPSequence, SMAPSequence, Hmap2Eval> as(dpm, opt);
+      dump("OPT", as);
+      const int Q = dpm.getQuerySize(), T = dpm.getTemplateSize();
+      printf("DIM %d %d\nH", Q, T);
+      for (int i = 0; i < Q; ++i) for (int j = 0; j < T; ++j) printf(" %08x", fbits(dpm.getCell(i, j)->score));
+      printf("\nS");
+      for (int i = 0; i < Q; ++i) for (int j = 0; j < T; ++j) printf(" %08x", fbits(dpm.getSim(i, j)));
+      printf("\n");
+      return 0;
+    }
+    AliParams p;
+    p.align_type = (align_t)atoi(argv[2]);
+    p.gap_init_penalty = (float)atof(argv[3]);
+    p.gap_extn_penalty = (float)atof(argv[4]);
+    direction_t dir = strcmp(argv[5], "rev") == 0 ? rev : fwd;
+    AASequence q, t;
+    q.seq_name = "query"; t.seq_name = "templ";
+    q.append("^"); q.append(argv[6]); q.append("$");
+    t.append("^"); t.append(argv[7]); t.append("$");
+    BlosumMatrix blosum(argv[8]);
+    typedef AASubstitutionEval<AASequence, AASequence> AAEval;
+    AAEval ev(p, blosum);
+    DPMatrix<AASequence, AASequence, AAEval> dpm(q, t, ev, dir, p.align_type);
+    const int Q = dpm.getQuerySize(), T = dpm.getTemplateSize();
+    printf("DIM %d %d\nH", Q, T);
+    for (int i = 0; i < Q; ++i) for (int j = 0; j < T; ++j) printf(" %08x", fbits(dpm.getCell(i, j)->score));
+    printf("\nPQ");
+    for (int i = 0; i < Q; ++i) for (int j = 0; j < T; ++j) printf(" %d", dpm.getCell(i, j)->prev_query_idx);
+    printf("\nPT");
+    for (int i = 0; i < Q; ++i) for (int j = 0; j < T; ++j) printf(" %d", dpm.getCell(i, j)->prev_template_idx);
+    printf("\n");
+    if (dir == fwd) {
+      Optimal<AASequence, AASequence, AAEval> opt(p.align_type);
+      AlignmentSet<AASequence, AASequence, AAEval> as(dpm, opt);
+      dump("OPT", as);
+      NOaliParams noa;
+      noa.number_suboptimal = 20; noa.delta_ratio = 0.3f;
+      UnconstrainedNearOptimal<AASequence, AASequence, AAEval> u(noa);
+      u.enumerate(dpm, as);
+      as.assignIdentity();
+      dump("UCW", as);
+    } else {
+      Optimal_Rev<AASequence, AASequence, AAEval> opt(p.align_type);
+      AlignmentSet<AASequence, AASequence, AAEval> as(dpm, opt);
+      dump("OPT", as);
+    }
+    return 0;
+  } catch (std::string e) {
+    printf("THROW %s\n", e.c_str());
+    return 0;
+  }
+}

@@ -1,0 +1,91 @@
+"""-m gpu: the C++11 host mirror (alignment-algos_amd/hostcpp) end to end: reference-style code — DPMatrix<S1,S2,E>,
+Optimal / Optimal_Rev, UnconstrainedNearOptimal, AlignmentSet, HMAPSequence files + Hmap2Eval — compiled with g++
+against the C ABI and run on the GPU (alignment-algos_amd/host_api_test), compared with the oracle bit for bit."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+import refrun
+from aln_amd.synth import homolog_pair, random_profile
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "alignment-algos_amd", "host_api_test")
+BLOSUM = os.path.join(ROOT, "tests", "golden", "BLOSUM62")
+
+
+def run(args):
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "alignment-algos_amd")])
+    r = subprocess.run([EXE] + [str(a) for a in args], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "THROW" not in r.stdout, r.stdout
+    return refrun.parse(r.stdout)
+
+
+def write_hmap(path, name, prof):
+    """HMAP text in the format hmapalib_seq.cpp:68-117,182-243 parses; returns the profile the parser will hold."""
+    n = len(prof["conf"]) - 2
+    pct = np.round(prof["aa"].astype(np.float64) * 100.0, 4).astype(np.float32)
+    held = {"aa": (pct / np.float32(100.0)).astype(np.float32), "sse": prof["sse"].copy(), "conf": prof["conf"].copy()}
+    # the parser's head/tail elements are value-initialised (zeros), not read from the file
+    for k in ("aa", "sse", "conf"):
+        held[k][0] = 0
+        held[k][-1] = 0
+    with open(path, "w") as f:
+        f.write("ID : %s\nDE : synthetic\nSR : none\nEVD: 0 0\nLEN: %d\n" % (name, n))
+        for i in range(1, n + 1):
+            f.write("%d A %s\n" % (i, " ".join("%.9g" % float(v) for v in pct[i])))
+            f.write(" - 4.73 0.34 0 0 0 0\n")
+            f.write(" * %s %.9g 0 0\n" % (" ".join("%.9g" % float(v) for v in prof["sse"][i]), float(prof["conf"][i])))
+        f.write("//\n")
+    return held
+
+
+@pytest.mark.parametrize("mode", [1, 4])
+def test_hmap2eval_through_host_classes(mode, tmp_path):
+    qp, tp = random_profile(91000, 37), random_profile(92000, 52)
+    qh = write_hmap(str(tmp_path / "q.hmap"), "query", qp)
+    th = write_hmap(str(tmp_path / "t.hmap"), "templ", tp)
+    got = run(["profile", mode, tmp_path / "q.hmap", tmp_path / "t.hmap"])
+    # HMAPaliParams defaults: alpha .5, beta 1, zero_shift .12, gaps 4.73 / 0.34 (hmap_eval.cpp:4-7, alib.cpp:17-18)
+    S = orc.hmap2_sim(qh, th, 0.5, 0.12)
+    tgi, tge = orc.hmap2_precalc(th, 4.73, 0.34, 1.0)
+    rc, D, PQ, PT = orc.dp_build(S, orc.Gap(mode, tgi=tgi, tge=tge))
+    assert np.array_equal(got["S"].view(np.uint32), S.view(np.uint32))
+    assert np.array_equal(got["H"].view(np.uint32), D.view(np.uint32))
+    rc2, sc, pairs = orc.optimal(D, PQ, PT, False)
+    a = got["sets"]["OPT"]["alis"][0]
+    assert a["score"].view(np.uint32) == sc.view(np.uint32) and np.array_equal(a["pairs"], pairs)
+
+
+@pytest.mark.parametrize("mode,gi,ge,direction", [(3, 11, 1, "fwd"), (4, 4.73, 0.34, "fwd"), (1, 11, 1, "rev"), (3, 4.73, 0.34, "rev")])
+def test_aa_path_through_host_classes(mode, gi, ge, direction, blosum62):
+    alpha, table = blosum62
+    q, t = homolog_pair(93000 + mode, 48, sub_rate=0.2, indel=3)
+    got = run(["aa", mode, gi, ge, direction, q, t, BLOSUM])
+    S = orc.sim_submatrix(q, t, alpha, table)
+    gap = orc.Gap(mode, gi, ge)
+    rc, D, PQ, PT = orc.dp_build(S, gap, orc.FWD if direction == "fwd" else orc.REV)   # B4 off by default in the host mirror
+    assert np.array_equal(got["H"].view(np.uint32), D.view(np.uint32))
+    assert np.array_equal(got["PQ"], PQ) and np.array_equal(got["PT"], PT)
+    rc2, sc, pairs = orc.optimal(D, PQ, PT, mode == 3, kind=direction)
+    a = got["sets"]["OPT"]["alis"][0]
+    assert a["score"].view(np.uint32) == sc.view(np.uint32) and np.array_equal(a["pairs"], pairs)
+    if direction == "fwd":
+        s = orc.AliSet()
+        s.push(pairs, sc)
+        orc.enumerate_noa("ucw", D, PQ, PT, S, gap, None, 20, 0.3, s)
+        s.identity(q, t)
+        u = got["sets"]["UCW"]
+        assert u["n"] == len(s)
+        for k in range(len(s)):
+            r = s.get(k)
+            assert u["alis"][k]["score"].view(np.uint32) == r["score"].view(np.uint32)
+            assert u["alis"][k]["uid"] == r["uid"]
+            assert np.array_equal(u["alis"][k]["pairs"], r["pairs"])
+            assert u["alis"][k]["identity"].view(np.uint32) == r["identity"].view(np.uint32)
