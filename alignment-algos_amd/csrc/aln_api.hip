@@ -87,7 +87,7 @@ int aln_batch_create(aln_ctx* ctx, const aln_seqs* queries, const aln_seqs* temp
   b->d_pairs = nullptr; b->d_qcodes = nullptr; b->d_tcodes = nullptr; b->d_H = nullptr; b->d_P = nullptr; b->d_S = nullptr;
   b->d_res = nullptr; b->d_table32 = nullptr; b->d_tablef = nullptr; b->d_tgi = nullptr; b->d_tge = nullptr;
   b->d_path = nullptr; b->d_bounds = nullptr; b->ev0 = nullptr; b->ev1 = nullptr;
-  b->have_dp = false; b->have_sub = false; b->islocal = false; b->alpha_n = 0; b->ptr_mode = 0;
+  b->have_dp = false; b->have_sub = false; b->islocal = false; b->alpha_n = 0; b->ptr_mode = 0; b->h_mode = 0;
   b->q_offsets.assign(queries->offsets, queries->offsets + queries->n_seqs + 1);
   b->t_offsets.assign(templates->offsets, templates->offsets + templates->n_seqs + 1);
   b->q_total = b->q_offsets.back();
@@ -255,6 +255,7 @@ int run_dp(aln_batch* b, bool simplane_integral) {
   }
   if (b->algo == ALN_DP_FAST && !fast) return ALN_E_NOT_INTEGRAL;
   b->ptr_mode = tagged ? 1 : 0;
+  b->h_mode = (tagged && b->islocal && !getenv("ALN_NO_H16")) ? 1 : 0;   // local scores of the tagged path are integers in [0, 65535]
   ALN_HIP_CHECK(ctx, hipEventRecord(b->ev0, ctx->stream));
   int rc = tagged ? launch_dp_affine_tag(b) : fast ? launch_dp_affine_int(b, !sub) : launch_dp_exact(b);
   if (rc) return rc;
@@ -352,16 +353,25 @@ int aln_batch_get_cells(aln_batch* b, int32_t pair, float* score, int32_t* prev_
   const size_t n = (size_t)d.Q * d.ld;
   std::vector<float> h(score ? n : 0);
   std::vector<uint32_t> p((prev_q || prev_t) ? n : 0);
-  if (score) ALN_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), b->d_H + d.plane_off, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (prev_q || prev_t) ALN_HIP_CHECK(ctx, hipMemcpyAsync(p.data(), b->d_P + d.plane_off, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (score) {
+    const size_t hsz = b->h_mode == 0 ? 4 : 2;
+    ALN_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), reinterpret_cast<const char*>(b->d_H) + (size_t)d.plane_off * hsz, n * hsz,
+                                      hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (prev_q || prev_t) {
+    // mode 1 planes hold 16-bit words at the same element offsets (aln_device.h load_ptr_word)
+    const size_t esz = b->ptr_mode == 0 ? 4 : 2;
+    ALN_HIP_CHECK(ctx, hipMemcpyAsync(p.data(), reinterpret_cast<const char*>(b->d_P) + (size_t)d.plane_off * esz, n * esz,
+                                      hipMemcpyDeviceToHost, ctx->stream));
+  }
   ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < d.Q; ++i)
     for (int j = 0; j < d.T; ++j) {
-      size_t s = (size_t)i * d.ld + j, o = (size_t)i * d.T + j;
-      if (score) score[o] = h[s];
+      const size_t o = (size_t)i * d.T + j;
+      if (score) score[o] = load_score(h.data(), 0, d.ld, i, j, b->h_mode);
       if (prev_q || prev_t) {
         int pq, pt;
-        decode_ptr(p[s], b->ptr_mode, i, j, pq, pt);
+        decode_ptr(load_ptr_word(p.data(), 0, d.ld, i, j, b->ptr_mode), b->ptr_mode, i, j, pq, pt);
         if (prev_q) prev_q[o] = pq;
         if (prev_t) prev_t[o] = pt;
       }

@@ -101,6 +101,31 @@ __host__ __device__ __forceinline__ void decode_ptr(uint32_t w, int mode, int i,
   else if (prio == 2) { pq = i - 1; pt = k; }
   else { pq = k; pt = j - 1; }
 }
+// In mode 1 the plane holds 16-bit words (13 used; 0xFFFF = untouched) at the same ELEMENT offsets as the fp32 score
+// plane, i.e. it occupies the first half of the bytes reserved for a 32-bit plane: 6 instead of 8 bytes per cell.
+__host__ __device__ __forceinline__ uint32_t load_ptr_word(const uint32_t* Pbase, int64_t plane_off, int ld, int i, int j, int mode) {
+  const size_t e = (size_t)plane_off + (size_t)i * ld + j;
+  if (mode == 0) return Pbase[e];
+  const uint16_t w = reinterpret_cast<const uint16_t*>(Pbase)[e];
+  return w == 0xFFFFu ? 0xFFFFFFFFu : (uint32_t)w;
+}
+__host__ __device__ __forceinline__ void store_ptr_word(uint32_t* Pbase, int64_t plane_off, int ld, int i, int j, int mode, uint32_t w) {
+  const size_t e = (size_t)plane_off + (size_t)i * ld + j;
+  if (mode == 0) Pbase[e] = w;
+  else reinterpret_cast<uint16_t*>(Pbase)[e] = (uint16_t)(w & 0xFFFFu);
+}
+// Score plane: hmode 0 = fp32; hmode 1 = uint16 at the same element offsets (local builds of the tagged kernel: every
+// score is an integer in [0, 65535]), 2 instead of 4 bytes per cell.
+__host__ __device__ __forceinline__ float load_score(const float* Hbase, int64_t plane_off, int ld, int i, int j, int hmode) {
+  const size_t e = (size_t)plane_off + (size_t)i * ld + j;
+  if (hmode == 0) return Hbase[e];
+  return (float)reinterpret_cast<const uint16_t*>(Hbase)[e];
+}
+__host__ __device__ __forceinline__ void store_score(float* Hbase, int64_t plane_off, int ld, int i, int j, int hmode, float v) {
+  const size_t e = (size_t)plane_off + (size_t)i * ld + j;
+  if (hmode == 0) Hbase[e] = v;
+  else reinterpret_cast<uint16_t*>(Hbase)[e] = (uint16_t)(int)v;
+}
 __host__ __device__ __forceinline__ uint32_t encode_ptr(int mode, int i, int j, int pq, int pt) {
   if (mode == 0) return ((uint32_t)pq << 16) | ((uint32_t)pt & 0xFFFFu);
   if (pq == i - 1 && pt == j - 1) return 3u << 11;

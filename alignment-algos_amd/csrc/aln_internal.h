@@ -83,6 +83,7 @@ struct aln_batch {
   aln::GapDev gapdev;
   bool islocal;
   int32_t ptr_mode;                            // encoding of the P plane words (aln_device.h decode_ptr)
+  int32_t h_mode;                              // score plane element type: 0 fp32, 1 uint16 (aln_device.h load_score)
   std::string kernel_name;
   hipEvent_t ev0, ev1;
   std::vector<int32_t> h_bounds;

@@ -19,7 +19,8 @@
 // decoded by aln_device.h::decode_ptr).  Gap constants and the substitution table are pre-shifted by 13, so all
 // additions are plain full-rate adds that leave the tags alone.
 //
-// Per cell: ~18 VALU instructions (was ~63); the kernel is HBM-write bound (8 B per cell: fp32 score + pointer word).
+// Per cell: ~18 VALU instructions (was ~63); the kernel is HBM-write bound.  The pointer word needs 13 bits, so the
+// plane is written as uint16 (0xFFFF = untouched): 6 bytes per cell reach HBM instead of the algorithmic 8.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -60,7 +61,7 @@ __device__ __forceinline__ int wave_incl_max_key(int v) {
   return v;
 }
 
-template <int NW, int R, bool LOCAL>
+template <int NW, int R, bool LOCAL, bool H16>
 __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
     const PairDesc* __restrict__ pairs, const uint8_t* __restrict__ qcodes, const uint8_t* __restrict__ tcodes,
     const int32_t* __restrict__ table32, float* __restrict__ Hbase, uint32_t* __restrict__ Pbase,
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
   const int cb = W0 + 4 * lane;
   const int gi = prm.gi, ge = prm.ge;
   float* __restrict__ H = Hbase + pd.plane_off;
-  uint32_t* __restrict__ P = Pbase + pd.plane_off;
+  uint16_t* __restrict__ P = reinterpret_cast<uint16_t*>(Pbase) + pd.plane_off;   // 16-bit pointer words (mode 1)
   const uint8_t* __restrict__ qc = qcodes + pd.q_off;
   const uint8_t* __restrict__ tc = tcodes + pd.t_off;
 
@@ -124,11 +125,17 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if (inrange[r]) {
-        const float sc = 1.0f / 8192.0f;       // exact: values are multiples of 2^13
-        float4 hv = make_float4((float)dk[r][0] * sc, (float)dk[r][1] * sc, (float)dk[r][2] * sc, (float)dk[r][3] * sc);
-        uint4 pv = make_uint4(pf[r][0], pf[r][1], pf[r][2], pf[r][3]);
-        *reinterpret_cast<float4*>(H + ro + 256 * r) = hv;
-        *reinterpret_cast<uint4*>(P + ro + 256 * r) = pv;
+        uint2 pv = make_uint2((pf[r][0] & 0xFFFFu) | (pf[r][1] << 16), (pf[r][2] & 0xFFFFu) | (pf[r][3] << 16));
+        if (H16) {                              // local: 0 <= score < 2^16 -> uint16 plane (2 B/cell)
+          uint2 hv = make_uint2(((uint32_t)dk[r][0] >> KB) | (((uint32_t)dk[r][1] >> KB) << 16),
+                                ((uint32_t)dk[r][2] >> KB) | (((uint32_t)dk[r][3] >> KB) << 16));
+          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(Hbase) + pd.plane_off + ro + 256 * r) = hv;
+        } else {
+          const float sc = 1.0f / 8192.0f;     // exact: values are multiples of 2^13
+          float4 hv = make_float4((float)dk[r][0] * sc, (float)dk[r][1] * sc, (float)dk[r][2] * sc, (float)dk[r][3] * sc);
+          *reinterpret_cast<float4*>(H + ro + 256 * r) = hv;
+        }
+        *reinterpret_cast<uint2*>(P + ro + 256 * r) = pv;
       }
     }
   };
@@ -343,14 +350,17 @@ template <int NW, int R>
 static int launch_tag_variant(aln_batch* b, const TagParams& prm) {
   dim3 grid(b->n_pairs), block(64 * NW);
   hipStream_t st = b->ctx->stream;
-  if (b->islocal)
-    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, true>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
+  if (b->islocal && b->h_mode == 1)
+    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, true, true>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
+                       b->d_H, b->d_P, b->d_res, prm);
+  else if (b->islocal)
+    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, true, false>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
                        b->d_H, b->d_P, b->d_res, prm);
   else
-    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, false>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
+    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, false, false>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
                        b->d_H, b->d_P, b->d_res, prm);
   char nm[96];
-  snprintf(nm, sizeof nm, "dp_affine_tag_kernel<NW=%d,R=%d,%s>", NW, R, b->islocal ? "local" : "global");
+  snprintf(nm, sizeof nm, "dp_affine_tag_kernel<NW=%d,R=%d,%s%s>", NW, R, b->islocal ? "local" : "global", b->h_mode == 1 ? ",h16" : "");
   b->kernel_name = nm;
   ALN_HIP_CHECK(b->ctx, hipGetLastError());
   return ALN_OK;

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(64) void dp_corner_kernel(const PairDesc* __restric
                                                        const float* __restrict__ tgi, const float* __restrict__ tge,
                                                        float* __restrict__ Hbase, uint32_t* __restrict__ Pbase,
                                                        const float* __restrict__ Sbase, PairResult* __restrict__ res,
-                                                       int islocal, int full_build, int rev, int bug_b4, int ptr_mode) {
+                                                       int islocal, int full_build, int rev, int bug_b4, int ptr_mode, int h_mode) {
   const PairDesc pd = pairs[blockIdx.x];
   EvalDev e = proto;
   e.Q = pd.Q; e.T = pd.T; e.ld = pd.ld;
@@ -26,8 +26,7 @@ __global__ __launch_bounds__(64) void dp_corner_kernel(const PairDesc* __restric
   e.tgi = tgi ? tgi + pd.t_off : nullptr;
   e.tge = tge ? tge + pd.t_off : nullptr;
   e.S = Sbase ? Sbase + pd.plane_off : nullptr;
-  float* H = Hbase + pd.plane_off;
-  uint32_t* P = Pbase + pd.plane_off;
+  auto HV = [&](int i, int j) -> float { return load_score(Hbase, pd.plane_off, pd.ld, i, j, h_mode); };
   const int ld = pd.ld, lane = threadIdx.x;
   const Frame f = {pd.q0, pd.q1, pd.t0, pd.t1, rev};
   const int nQ = f.nQ(), nT = f.nT();
@@ -56,14 +55,14 @@ __global__ __launch_bounds__(64) void dp_corner_kernel(const PairDesc* __restric
     for (int idx = lane; idx < ncand; idx += 64) {
       float s;
       if (idx == 0) {
-        s = H[(size_t)f.rq(nQ - 1) * ld + f.rt(nT - 1)] + sc;
+        s = HV(f.rq(nQ - 1), f.rt(nT - 1)) + sc;
       } else if (idx <= ndel) {
-        s = H[(size_t)f.rq(nQ - 1) * ld + f.rt(idx)];
+        s = HV(f.rq(nQ - 1), f.rt(idx));
         s -= frame_del(e, f, idx, nT);
         s += sc;
       } else {
         int k = idx - ndel;
-        s = H[(size_t)f.rq(k) * ld + f.rt(nT - 1)];
+        s = HV(f.rq(k), f.rt(nT - 1));
         s -= frame_ins(e, f, k, nQ, nT - 1, nT);
         s += sc;
       }
@@ -87,11 +86,12 @@ __global__ __launch_bounds__(64) void dp_corner_kernel(const PairDesc* __restric
     }
   }
   if (lane == 0) {
-    H[(size_t)fq * ld + ft] = corner;
+    store_score(Hbase, pd.plane_off, ld, fq, ft, h_mode, corner);
     {
       int cpq, cpt;
       decode_ptr(cptr, 0, fq, ft, cpq, cpt);
-      P[(size_t)fq * ld + ft] = encode_ptr(ptr_mode, fq, ft, cpq, cpt);   // the final cell speaks the plane's pointer dialect
+      // the final cell speaks the plane's pointer dialect
+      store_ptr_word(Pbase, pd.plane_off, ld, fq, ft, ptr_mode, encode_ptr(ptr_mode, fq, ft, cpq, cpt));
     }
     PairResult r = res[blockIdx.x];
     r.corner = corner;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64) void dp_corner_kernel(const PairDesc* __restric
       // find_max: the seed keeps ties, otherwise the first strictly greater cell of the scan wins.
       // forward (optimal.h:111-113): seed (Q-2,T-2); reverse (optimal_rev.h:120-122): seed (0,0) = the final cell.
       const int sq = rev ? fq : pd.Q - 2, st = rev ? ft : pd.T - 2;
-      const float seed = rev ? corner : H[(size_t)sq * ld + st];
+      const float seed = rev ? corner : HV(sq, st);
       if (r.part_pos != 0xFFFFFFFFu && seed < r.part_max) {
         r.best = r.part_max; r.best_q = (int)(r.part_pos >> 16); r.best_t = (int)(r.part_pos & 0xFFFFu);
       } else {
@@ -125,7 +125,7 @@ int launch_dp_corner(aln_batch* b) {
   hipLaunchKernelGGL(dp_corner_kernel, dim3(b->n_pairs), dim3(64), 0, b->ctx->stream, b->d_pairs, proto,
                      sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr,
                      tpos ? b->d_tge : nullptr, b->d_H, b->d_P, sub ? nullptr : b->d_S, b->d_res,
-                     (int)b->islocal, (int)!b->have_sub, (int)(b->direction == ALN_REV), (int)b->bug_b4, (int)b->ptr_mode);
+                     (int)b->islocal, (int)!b->have_sub, (int)(b->direction == ALN_REV), (int)b->bug_b4, (int)b->ptr_mode, (int)b->h_mode);
   ALN_HIP_CHECK(b->ctx, hipGetLastError());
   return ALN_OK;
 }

@@ -31,6 +31,7 @@ struct EnumArgs {
   uint32_t* stack; uint32_t stack_cap;   // frames of kFrameWords words
   const uint8_t* flags; // T bytes
   int ptr_mode;         // pointer word encoding of the P plane
+  int h_mode;           // score plane element type
   int32_t* out;         // [0] = set size, [1] = nodes used, [2] = status
 };
 
@@ -55,8 +56,7 @@ __global__ __launch_bounds__(64) void enumerate_kernel(const PairDesc* __restric
   e.tgi = tgi ? tgi + pd.t_off : nullptr;
   e.tge = tge ? tge + pd.t_off : nullptr;
   e.S = Sbase ? Sbase + pd.plane_off : nullptr;
-  const float* H = Hbase + pd.plane_off;
-  const uint32_t* P = Pbase + pd.plane_off;
+  auto HV = [&](int i, int j) -> float { return load_score(Hbase, pd.plane_off, pd.ld, i, j, a.h_mode); };
   const int ld = pd.ld, lane = threadIdx.x;
   const int Q = pd.Q, T = pd.T;
   const bool cw = a.kind == ALN_ENUM_CW;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64) void enumerate_kernel(const PairDesc* __restric
   if (lane == 0) { st_u(&a.head[a.first_slot], kNoNode); st_f(&a.score[a.first_slot], 0.f); }
   sync_mem();
 
-  const float top = H[(size_t)(Q - 1) * ld + (T - 1)];
+  const float top = HV(Q - 1, T - 1);
   float thr = (1.f - a.delta_ratio) * top;       // cw.h:86-88
   { float alt = top - 0.1f; thr = (alt < thr) ? alt : thr; }
 
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64) void enumerate_kernel(const PairDesc* __restric
     prepend(k0, q0, t0);
     prepend(k0, 0, 0);
     float s = ld_f(&a.score[k0]);
-    s += H[(size_t)q0 * ld + t0];
+    s += HV(q0, t0);
     set_score(k0, s);
   };
   // the pointer-following loop of opt_path (cw.h:242-272 / ucw.h:207-228); returns the cell it stopped at
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64) void enumerate_kernel(const PairDesc* __restric
       if (cw && !force && ((a.flags[t0] != 0) == flag)) break;   // the template's SuboptFlags bit flipped: branch point
       prepend(k0, q0, t0);
       sc += dev_sim(e, q0, t0);
-      const uint32_t p = P[(size_t)q0 * ld + t0];
+      const uint32_t p = load_ptr_word(Pbase, pd.plane_off, ld, q0, t0, a.ptr_mode);
       int pq, pt;
       decode_ptr(p, a.ptr_mode, q0, t0, pq, pt);
       float g;
@@ -161,16 +161,16 @@ __global__ __launch_bounds__(64) void enumerate_kernel(const PairDesc* __restric
       if (idx < ncand) {
         if (idx == 0) {                                     // match, cw.h:151-162
           pq = q0 - 1; pt = t0 - 1;
-          const float fsc = H[(size_t)pq * ld + pt];
+          const float fsc = HV(pq, pt);
           ok = fsc + r > thr;
         } else if (idx <= ndel) {                           // deletions i = t0-2 .. 1, cw.h:166-178
           pq = q0 - 1; pt = t0 - 1 - idx;
-          const float fsc = H[(size_t)pq * ld + pt];
+          const float fsc = HV(pq, pt);
           g = dev_deletion(e, pt, t0);
           ok = fsc + r - g > thr;
         } else {                                            // insertions j = q0-2 .. 1, cw.h:182-194
           pq = q0 - 2 - (idx - ndel - 1); pt = t0 - 1;
-          const float fsc = H[(size_t)pq * ld + pt];
+          const float fsc = HV(pq, pt);
           g = dev_insertion(e, pq, q0, pt, t0);
           ok = fsc + r - g > thr;
         }
@@ -291,6 +291,7 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   else ETRY(hipMemsetAsync(d_flags, 1, (size_t)d.T, ctx->stream));
   a.flags = d_flags;
   a.ptr_mode = b->ptr_mode;
+  a.h_mode = b->h_mode;
   a.out = d_out;
 
   EvalDev proto = {};

@@ -18,14 +18,13 @@ struct TbParams {
   int rev;          // pointers lead towards larger indices (reverse build, Optimal_Rev)
   int stride;       // capacity in pairs of each pair's output list
   int ptr_mode;     // pointer word encoding of the P plane
+  int h_mode;       // score plane element type (aln_device.h load_score)
 };
 
 __global__ __launch_bounds__(64) void traceback_kernel(const PairDesc* __restrict__ pairs, const float* __restrict__ Hbase,
                                                        const uint32_t* __restrict__ Pbase, PairResult* __restrict__ res,
                                                        int32_t* __restrict__ out, TbParams prm) {
   const PairDesc pd = pairs[blockIdx.x];
-  const float* H = Hbase + pd.plane_off;
-  const uint32_t* P = Pbase + pd.plane_off;
   const int ld = pd.ld, lane = threadIdx.x;
   int32_t* o = out + (size_t)blockIdx.x * prm.stride * 2;
   PairResult r = res[blockIdx.x];
@@ -50,7 +49,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairDesc* __restric
     const int cq = q + sg * lane, ct = t + sg * lane;
     const bool valid = cq >= 0 && ct >= 0 && cq < Q && ct < T;
     uint32_t p = kNullPtr; float h = 0.f;
-    if (valid) { p = P[(size_t)cq * ld + ct]; h = H[(size_t)cq * ld + ct]; }
+    if (valid) { p = load_ptr_word(Pbase, pd.plane_off, ld, cq, ct, prm.ptr_mode); h = load_score(Hbase, pd.plane_off, ld, cq, ct, prm.h_mode); }
     const float hnext = __shfl_down(h, 1);      // score of the diagonal neighbour (lane+1's cell)
     const bool active = valid && before_stop(cq);   // the while loop would process this cell
     const int nq_ = cq + sg, nt_ = ct + sg;
@@ -80,7 +79,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairDesc* __restric
     const int nq = jq, nt = jt;
     if (pL == kNullPtr) { lq = -1; lt = -1; if (!prm.islocal) status = ALN_E_STARTPAIR; break; }
     if (prm.islocal) {
-      const float hn = H[(size_t)nq * ld + nt];
+      const float hn = load_score(Hbase, pd.plane_off, ld, nq, nt, prm.h_mode);
       if (hn <= 0.f) { lq = nq; lt = nt; break; }
     }
     emit1(nq, nt);
@@ -105,6 +104,7 @@ int launch_traceback(aln_batch* b, bool subali) {
   prm.rev = (b->direction == ALN_REV && !subali) ? 1 : 0;
   prm.stride = b->path_stride;
   prm.ptr_mode = b->ptr_mode;
+  prm.h_mode = b->h_mode;
   hipLaunchKernelGGL(traceback_kernel, dim3(b->n_pairs), dim3(64), 0, b->ctx->stream, b->d_pairs, b->d_H, b->d_P,
                      b->d_res, b->d_path, prm);
   ALN_HIP_CHECK(b->ctx, hipGetLastError());
