@@ -161,7 +161,8 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_int_kernel(
     }
     if (NW > 1) {
       if (lane == 63) { xch[par][w][0] = sv; xch[par][w][1] = sa; xch[par][w][2] = hB; xch[par][w][3] = (int)pB; }
-      __syncthreads();
+      // LDS-only barrier: a __syncthreads() would also wait (vmcnt(0)) for this row's global stores to be acknowledged
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (w > 0) {
         int fv = kNeg, fa = -1;                 // prefix over columns 1 .. W0-1
         for (int v = 0; v < w; ++v) {

@@ -68,6 +68,7 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
     PairResult* __restrict__ res, TagParams prm) {
   using namespace tag;
   __shared__ int tab[32 * 32];          // substitution scores << 13
+  __shared__ uint8_t qcs[2048];         // the query's residue codes (Q <= 2048): one LDS byte per row instead of a global load
   __shared__ int xch[2][NW][4];
   __shared__ int red[NW][2];
 
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
   const uint8_t* __restrict__ tc = tcodes + pd.t_off;
 
   for (int k = threadIdx.x; k < 32 * 32; k += 64 * NW) tab[k] = table32[k] * (1 << KB);
+  for (int k = threadIdx.x; k < Q; k += 64 * NW) qcs[k] = qc[k];
   __syncthreads();
 
   // ---- static per-column constants -----------------------------------------------------------------
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
   int dk[R][4];         // D[i-1][c] << 13 (low bits zero)
   int gmx[R][4];        // running max over k of key(D[k][c] + ge*k, insertion, 2047-k)
   int cvk[R];           // lane-exclusive prefix key of the row in dk (A-space), per group
+  int ak[R][4];         // A-space keys of the row in dk: dk + GK (column 0 / wave firsts handled where they are used)
   uint32_t pf[R][4];    // pointer words of the row being finished
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -149,13 +152,11 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
     int sk = NEGK;     // scalar carry: prefix key over this wave's earlier groups
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      int tk = NEGK;
 #pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        int A = dk[r][x] + GK[r][x];
-        if (r == 0 && x == 0) A = (lane == 0) ? NEGK : A;   // column 0 is never a source; wave firsts are folded below
-        tk = max(tk, A);
-      }
+      for (int x = 0; x < 4; ++x) ak[r][x] = dk[r][x] + GK[r][x];
+      int a0 = ak[r][0];
+      if (r == 0) a0 = (lane == 0) ? NEGK : a0;             // column 0 is never a source; wave firsts are folded below
+      const int tk = max(max(a0, ak[r][1]), max(ak[r][2], ak[r][3]));
       const int ik = wave_incl_max_key(tk);
       const int ek = tdpp<0x138>(NEGK, ik);                 // wave_shr:1 -> exclusive
       cvk[r] = max(sk, ek);
@@ -163,7 +164,8 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
     }
     if (NW > 1) {
       if (lane == 63) { xch[par][w][0] = sk; xch[par][w][1] = dB; xch[par][w][2] = (int)pB; }
-      __syncthreads();
+      // LDS-only barrier: a __syncthreads() would also wait (vmcnt(0)) for this row's global stores to be acknowledged
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (w > 0) {
         int fk = NEGK;                                      // prefix over columns 1 .. W0-1
         for (int v = 0; v < w; ++v) {
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
         }
         const int d0 = xch[par][w - 1][1];
         const uint32_t p0 = (uint32_t)xch[par][w - 1][2];
-        if (lane == 0) { dk[0][0] = d0; pf[0][0] = p0; }
+        if (lane == 0) { dk[0][0] = d0; pf[0][0] = p0; ak[0][0] = d0 + GK[0][0]; }
         const int f2 = max(fk, d0 + (((ge * W0) * (1 << KB)) | P_DEL | (TAGMAX - W0)));
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -189,9 +191,7 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
     if (LOCAL) {
       int rm = 0;
 #pragma unroll
-      for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) rm = max(rm, dk[r][x]);
+      for (int r = 0; r < R; ++r) { rm = max(max(rm, dk[r][0]), dk[r][1]); rm = max(max(rm, dk[r][2]), dk[r][3]); }   // 2 x v_max3 per group
       if (rm > lmax) {                                      // rare: resolve the first column of this lane at the new maximum
         lmax = rm;
         int cfirst = 0x7FFFFFFF;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
   store_row(0);   // untouched cells: score 0, null pointer (dpmatrix.cpp:17-25)
   if (Q >= 3) {
     // row 1 (dpmatrix.h:409-418 / :579-590): match at (1,1), otherwise one deletion from the origin -> pointer (0,0)
-    const int qrow = (int)qc[1] * 128;
+    const int qrow = (int)qcs[1] * 128;
     auto row1 = [&](int c, int sK, int& dkv, uint32_t& pv) {
       const int cost = (c >= 2 && !prm.free_del) ? ((gi + ge * (c - 2)) * (1 << KB)) : 0;
       int v = sK - cost;
@@ -228,10 +228,10 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
   }
 
   // ---- interior rows 2 .. Q-2 (dpmatrix.h:447-486 / :607-649) ---------------------------------------------
-  int qcode_next = (Q >= 4) ? (int)qc[2] : 0;
+  int qcode_next = (Q >= 4) ? (int)qcs[2] : 0;
   for (int i = 2; i <= Q - 2; ++i) {
     const int qrow = qcode_next * 128;
-    if (i + 1 <= Q - 2) qcode_next = (int)qc[i + 1];
+    if (i + 1 <= Q - 2) qcode_next = (int)qcs[i + 1];
     const int FK = (gi + ge * (i - 2)) * (1 << KB);                                   // F = gmx - FK
     const int RK = ((ge * (i - 1)) * (1 << KB)) | P_INS | (TAGMAX - (i - 1));         // key(D[i-1][c] + ge (i-1), insertion from row i-1)
     const int colK = prm.free_ins ? 0 : FK;                                     // column 1: one insertion from the origin
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
         const int m = dk[r][x];
-        int A = m + GK[r][x];
+        int A = ak[r][x];
         if (r == 0 && x == 0) A = (cb == 0) ? NEGK : A;     // column 0 is never a source (dpmatrix.h:459 starts at t0+1)
         const int e = pv - EK[r][x];
         const int f = gmx[r][x] - FK;
