@@ -63,7 +63,7 @@ EXPORTS = [
     "aln_ctx_create", "aln_ctx_destroy", "aln_error_string", "aln_last_error", "aln_ctx_synchronize", "aln_has_gfx950",
     "aln_batch_create", "aln_batch_destroy", "aln_batch_n_pairs", "aln_batch_device_bytes", "aln_batch_dp",
     "aln_batch_reevaluate", "aln_batch_dp_kernel_name", "aln_batch_dp_sub", "aln_batch_get_cells", "aln_batch_get_sim",
-    "aln_batch_get_corner_scores", "aln_batch_optimal", "aln_batch_optimal_subali", "aln_batch_enumerate", "aln_identity",
+    "aln_batch_get_corner_scores", "aln_batch_optimal", "aln_batch_optimal_subali", "aln_batch_enumerate", "aln_batch_enumerate_all", "aln_batch_last_enum_ms", "aln_identity",
     "aln_gapped_length", "aln_gapped_strings", "aln_hmap2_gap_arrays", "aln_score_all_vs_all", "aln_batch_last_dp_ms", "aln_batch_dp_algorithmic_bytes", "aln_batch_cells",
 ]
 
@@ -112,6 +112,9 @@ def lib():
         L.aln_batch_optimal_subali.argtypes = [C.c_void_p, _fp, _ip, _ip, C.c_int32, _ip]
         L.aln_batch_enumerate.argtypes = [C.c_void_p, C.c_int32, C.POINTER(AlnNoa), C.POINTER(C.c_uint8), C.POINTER(AlnAlignment),
                                           C.c_int32, _ip, C.c_int64, _ip]
+        L.aln_batch_enumerate_all.argtypes = [C.c_void_p, C.POINTER(AlnNoa), C.POINTER(C.c_uint8), C.c_int32, C.c_uint32, C.c_uint32,
+                                              C.c_int32, _ip, _fp, _ip, _ip, C.c_int32, _ip]
+        L.aln_batch_last_enum_ms.argtypes = [C.c_void_p, _fp, _fp]
         L.aln_identity.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, _ip, C.c_int32]
         L.aln_gapped_length.argtypes = [C.c_int32, C.POINTER(AlnAlignment), C.c_int32, _ip]
         L.aln_gapped_strings.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(AlnAlignment), C.c_int32, _ip,
@@ -354,6 +357,37 @@ class Batch:
             res.append({"score": np.float32(a.score), "identity": np.float32(a.identity), "uid": a.uid,
                         "pairs": pairs[a.pair_off:a.pair_off + a.n_pairs].copy()})
         return res
+
+    def enumerate_all(self, kind, number_suboptimal, delta_ratio, flags=None, K=None, user_limit=0, node_cap=0, ali_cap=0,
+                      want_pairs=True, raise_on_overflow=True):
+        """aln_batch_enumerate_all: every pair of the batch in one launch.  flags: None, one shared row, or an
+        [n, stride] uint8 array.  -> n_out[n], scores[n,K], lengths[n,K], pairs[n,K,stride,2] or None, status[n]"""
+        noa = AlnNoa(ENUM_CW if kind == "cw" else ENUM_UCW, int(number_suboptimal), float(np.float32(delta_ratio)), int(user_limit), -1, None)
+        if K is None:
+            K = max(int(number_suboptimal), 1) + 2
+        fl, fstride = None, 0
+        if flags is not None:
+            fl = np.ascontiguousarray(flags, dtype=np.uint8)
+            fstride = fl.shape[1] if fl.ndim == 2 else 0
+        if not hasattr(self, "_stride"):
+            self._stride = max(min(max(self.dims(p)[0] for p in range(self.n)), max(self.dims(p)[1] for p in range(self.n))) + 3, 4) if self.n else 4
+        stride = self._stride
+        n_out = np.zeros(self.n, dtype=np.int32)
+        scores = np.zeros((self.n, K), dtype=np.float32)
+        lengths = np.zeros((self.n, K), dtype=np.int32)
+        status = np.zeros(self.n, dtype=np.int32)
+        pairs = np.zeros((self.n, K, stride, 2), dtype=np.int32) if want_pairs else None
+        rc = lib().aln_batch_enumerate_all(self.h, C.byref(noa), fl.ctypes.data_as(C.POINTER(C.c_uint8)) if fl is not None else None, fstride,
+                                           int(node_cap), int(ali_cap), K, _i(n_out), _f(scores), _i(lengths),
+                                           _i(pairs) if want_pairs else None, stride, _i(status))
+        if rc != 0 and (raise_on_overflow or rc != E_OVERFLOW):
+            _check(rc, self.ctx.h)
+        return n_out, scores, lengths, pairs, status
+
+    def last_enum_ms(self):
+        a, b = C.c_float(0), C.c_float(0)
+        _check(lib().aln_batch_last_enum_ms(self.h, C.byref(a), C.byref(b)), self.ctx.h)
+        return a.value, b.value
 
     def optimal(self, want_pairs=True, subali=False):
         """-> scores[n], list of pair arrays (list order), status[n]"""

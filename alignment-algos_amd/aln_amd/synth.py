@@ -109,3 +109,19 @@ def random_profile(seed, n):
     sse = (s / s.sum(axis=1, keepdims=True)).astype(np.float32)
     conf = u[L * 43:L * 44].astype(np.float32)
     return {"aa": aa, "sse": sse, "conf": conf}
+
+
+def make_subopt_regions(T, regs):
+    """SuboptFlags for config 4 as the drivers make them (gn2.cpp:268-283): T template positions divided into `regs`
+    alternating regions; the float comparisons are the reference's (fp32)."""
+    length = np.float32(T) / np.float32(regs)
+    flags = np.zeros(T, dtype=np.uint8)
+    flag = True
+    place = np.float32(length)
+    for i in range(T):
+        flags[i] = flag
+        if np.float32(i) > place:
+            flag = not flag
+            place = np.float32(place + length)
+    flags[T - 1] = 1
+    return flags

@@ -86,6 +86,7 @@ struct aln_batch {
   int32_t h_mode;                              // score plane element type: 0 fp32, 1 uint16 (aln_device.h load_score)
   std::string kernel_name;
   hipEvent_t ev0, ev1;
+  float enum_search_ms = 0.f, enum_unroll_ms = 0.f;   // last aln_batch_enumerate_all
   std::vector<int32_t> h_bounds;
   // retained similarity description for reevaluate()
   std::vector<float> h_table; int32_t alpha_n; std::string alphabet;

@@ -33,6 +33,8 @@ struct EnumArgs {
   int ptr_mode;         // pointer word encoding of the P plane
   int h_mode;           // score plane element type
   int32_t* out;         // [0] = set size, [1] = nodes used, [2] = status
+  // batched launches (one block per pair): block b works on pair pair0 + b with the b-th slice of every pool
+  int flags_stride;     // bytes between two pairs' flag rows (0: every pair shares one row)
 };
 
 constexpr uint32_t kNoNode = 0xFFFFFFFFu;
@@ -48,6 +50,15 @@ __global__ __launch_bounds__(64) void enumerate_kernel(const PairDesc* __restric
                                                        const float* __restrict__ tgi, const float* __restrict__ tge,
                                                        const float* __restrict__ Hbase, const uint32_t* __restrict__ Pbase,
                                                        const float* __restrict__ Sbase, EnumArgs a) {
+  pair += (int)blockIdx.x;
+  {
+    const size_t bi = blockIdx.x;
+    a.node_pair += bi * a.node_cap; a.node_next += bi * a.node_cap;
+    a.head += bi * a.ali_cap; a.score += bi * a.ali_cap;
+    a.stack += bi * (size_t)a.stack_cap * kFrameWords;
+    a.flags += bi * (size_t)a.flags_stride;
+    a.out += bi * 4;
+  }
   const PairDesc pd = pairs[pair];
   EvalDev e = proto;
   e.Q = pd.Q; e.T = pd.T; e.ld = pd.ld;
@@ -383,5 +394,149 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
     out[k].identity = aln_identity(qs.c_str(), d.Q, ts.c_str(), d.T, pairs + 2 * off, len);
     off += len;
   }
+  return ALN_OK;
+}
+
+
+// ---- batched form (BASELINE config 4): every pair of the batch in one launch ----------------------------------
+namespace aln {
+// one wave per (pair, slot): slot's alignment index comes from sel[]; -1 = empty, 0 = the pair's Optimal alignment
+// (taken from the traceback list, which is stored end -> start), otherwise a trie walk.
+__global__ __launch_bounds__(64) void enum_unroll_all_kernel(const uint32_t* __restrict__ node_pair, const uint32_t* __restrict__ node_next,
+                                                             const uint32_t* __restrict__ head, uint32_t node_cap, uint32_t ali_cap,
+                                                             const int32_t* __restrict__ sel, int K, const int32_t* __restrict__ path,
+                                                             int path_stride, const PairResult* __restrict__ res,
+                                                             int32_t* __restrict__ out_pairs, int32_t* __restrict__ out_n, int stride) {
+  const int p = blockIdx.y, k = blockIdx.x;
+  const int idx = sel[(size_t)p * K + k];
+  int32_t* o = out_pairs ? out_pairs + ((size_t)p * K + k) * stride * 2 : nullptr;
+  if (idx < 0) { if (threadIdx.x == 0) out_n[(size_t)p * K + k] = 0; return; }
+  if (idx == 0) {
+    const int n = res[p].n_path;
+    const int32_t* src = path + (size_t)p * path_stride * 2;
+    if (o) for (int i = threadIdx.x; i < n && i < stride; i += 64) { o[2 * i] = src[2 * (n - 1 - i)]; o[2 * i + 1] = src[2 * (n - 1 - i) + 1]; }
+    if (threadIdx.x == 0) out_n[(size_t)p * K + k] = n;
+    return;
+  }
+  if (threadIdx.x != 0) return;
+  const uint32_t* np_ = node_pair + (size_t)p * node_cap;
+  const uint32_t* nn_ = node_next + (size_t)p * node_cap;
+  uint32_t node = head[(size_t)p * ali_cap + idx];
+  int n = 0;
+  while (node != kNoNode && n < stride) {
+    if (o) { uint32_t w = np_[node]; o[2 * n] = (int32_t)(w >> 16); o[2 * n + 1] = (int32_t)(w & 0xFFFFu); }
+    ++n;
+    node = nn_[node];
+  }
+  out_n[(size_t)p * K + k] = (node == kNoNode) ? n : -1;
+}
+}  // namespace aln
+
+extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const uint8_t* flags, int32_t flags_stride,
+                                       uint32_t node_cap_per_pair, uint32_t ali_cap_per_pair, int32_t K, int32_t* n_out, float* scores,
+                                       int32_t* lengths, int32_t* pairs, int32_t pair_stride, int32_t* status) {
+  if (!b || !noa || !n_out || !scores || !lengths || !status || K <= 0) return ALN_E_ARG;
+  if (!b->have_dp || b->have_sub || b->direction != ALN_FWD) return ALN_E_STATE;
+  if (noa->kind == ALN_ENUM_CW && !flags) return ALN_E_ARG;
+  if (pairs && pair_stride < b->path_stride) return ALN_E_ARG;
+  aln_ctx* ctx = b->ctx;
+  ALN_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int n = b->n_pairs;
+  if (n == 0) return ALN_OK;
+  // every set starts with the pair's Optimal alignment (aa_ali.cpp:83)
+  int rc = launch_traceback(b, false);
+  if (rc) return rc;
+  const uint32_t user_limit = noa->user_limit ? noa->user_limit : (noa->kind == ALN_ENUM_CW ? 1000000u : 100000u);
+  EnumArgs a = {};
+  a.kind = noa->kind; a.user_limit = user_limit; a.delta_ratio = noa->delta_ratio; a.first_slot = 1;
+  a.ali_cap = ali_cap_per_pair ? ali_cap_per_pair : 65536u;
+  a.node_cap = node_cap_per_pair ? node_cap_per_pair : (1u << 20);
+  a.stack_cap = (uint32_t)(b->maxQ + b->maxT + 8);
+  a.ptr_mode = b->ptr_mode; a.h_mode = b->h_mode;
+  a.flags_stride = flags ? flags_stride : 0;
+  uint8_t* d_flags = nullptr; int32_t *d_out = nullptr, *d_sel = nullptr, *d_lists = nullptr, *d_lens = nullptr;
+  hipEvent_t evs[4] = {nullptr, nullptr, nullptr, nullptr};
+  auto cleanup = [&]() {
+    hipFree(a.node_pair); hipFree(a.node_next); hipFree(a.head); hipFree(a.score); hipFree(a.stack); hipFree(d_flags); hipFree(d_out);
+    hipFree(d_sel); hipFree(d_lists); hipFree(d_lens);
+    for (auto ev : evs) if (ev) hipEventDestroy(ev);
+  };
+#define BTRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup(); return ALN_E_HIP; } } while (0)
+  BTRY(hipMalloc((void**)&a.node_pair, (size_t)n * a.node_cap * 4));
+  BTRY(hipMalloc((void**)&a.node_next, (size_t)n * a.node_cap * 4));
+  BTRY(hipMalloc((void**)&a.head, (size_t)n * a.ali_cap * 4));
+  BTRY(hipMalloc((void**)&a.score, (size_t)n * a.ali_cap * 4));
+  BTRY(hipMalloc((void**)&a.stack, (size_t)n * a.stack_cap * kFrameWords * 4));
+  const size_t fl_bytes = flags ? (flags_stride ? (size_t)n * flags_stride : (size_t)b->maxT) : (size_t)b->maxT;
+  BTRY(hipMalloc((void**)&d_flags, fl_bytes));
+  BTRY(hipMalloc((void**)&d_out, (size_t)n * 16));
+  if (flags) BTRY(hipMemcpyAsync(d_flags, flags, fl_bytes, hipMemcpyHostToDevice, ctx->stream));
+  else BTRY(hipMemsetAsync(d_flags, 1, fl_bytes, ctx->stream));
+  a.flags = d_flags; a.out = d_out;
+  EvalDev proto = {};
+  proto.model = b->gapdev.model; proto.align_type = b->gapdev.align_type;
+  proto.gi = b->gapdev.gi; proto.ge = b->gapdev.ge;
+  proto.sim_kind = (b->sim_kind == ALN_SIM_SUBMATRIX) ? ALN_SIM_SUBMATRIX : ALN_SIM_MATRIX;
+  proto.tablef = b->d_tablef;
+  const bool sub = b->sim_kind == ALN_SIM_SUBMATRIX;
+  const bool tpos = b->gapdev.model == ALN_GAP_AFFINE_TPOS_MIN;
+  for (auto& ev : evs) BTRY(hipEventCreate(&ev));
+  BTRY(hipEventRecord(evs[0], ctx->stream));
+  hipLaunchKernelGGL(enumerate_kernel, dim3(n), dim3(64), 0, ctx->stream, b->d_pairs, 0, proto, sub ? b->d_qcodes : nullptr,
+                     sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr, b->d_H, b->d_P,
+                     sub ? nullptr : b->d_S, a);
+  BTRY(hipGetLastError());
+  BTRY(hipEventRecord(evs[1], ctx->stream));
+  std::vector<int32_t> hout((size_t)n * 4);
+  std::vector<PairResult> res(n);
+  BTRY(hipMemcpyAsync(hout.data(), d_out, hout.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  BTRY(hipMemcpyAsync(res.data(), b->d_res, sizeof(PairResult) * n, hipMemcpyDeviceToHost, ctx->stream));
+  BTRY(hipStreamSynchronize(ctx->stream));
+  // per pair: sortSet on (score, index) keys, pick the survivors
+  std::vector<int32_t> sel((size_t)n * K, -1);
+  std::vector<float> sc;
+  int worst = ALN_OK;
+  for (int p = 0; p < n; ++p) {
+    status[p] = hout[4 * p + 2] ? hout[4 * p + 2] : res[p].status;
+    n_out[p] = 0;
+    if (status[p] != 0) { worst = status[p]; continue; }
+    const int n_as = hout[4 * p];
+    sc.resize(n_as);
+    BTRY(hipMemcpy(sc.data() + 1, a.score + (size_t)p * a.ali_cap + 1, (size_t)(n_as - 1) * 4, hipMemcpyDeviceToHost));
+    sc[0] = b->islocal ? res[p].best : res[p].corner;
+    std::vector<SortKey> keys(n_as);
+    for (int k = 0; k < n_as; ++k) { keys[k].score = sc[k]; keys[k].idx = k; }
+    const int mx = noa->number_suboptimal;
+    if (mx >= n_as) std::sort(keys.begin(), keys.end());
+    else if (mx > 0) { std::partial_sort(keys.begin(), keys.begin() + mx, keys.end()); keys.erase(keys.begin() + mx, keys.end()); }
+    int keep = (int)keys.size();
+    if (keep > K) { status[p] = ALN_E_OVERFLOW; worst = ALN_E_OVERFLOW; keep = K; }
+    n_out[p] = keep;
+    for (int k = 0; k < keep; ++k) { sel[(size_t)p * K + k] = keys[k].idx; scores[(size_t)p * K + k] = keys[k].score; }
+  }
+  // unroll every survivor on the device
+  BTRY(hipMalloc((void**)&d_sel, sel.size() * 4));
+  BTRY(hipMalloc((void**)&d_lens, sel.size() * 4));
+  if (pairs) BTRY(hipMalloc((void**)&d_lists, sel.size() * (size_t)pair_stride * 8));
+  BTRY(hipMemcpyAsync(d_sel, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  BTRY(hipEventRecord(evs[2], ctx->stream));
+  hipLaunchKernelGGL(enum_unroll_all_kernel, dim3(K, n), dim3(64), 0, ctx->stream, a.node_pair, a.node_next, a.head, a.node_cap, a.ali_cap,
+                     d_sel, K, b->d_path, b->path_stride, b->d_res, d_lists, d_lens, pairs ? pair_stride : (1 << 30));
+  BTRY(hipGetLastError());
+  BTRY(hipEventRecord(evs[3], ctx->stream));
+  BTRY(hipMemcpyAsync(lengths, d_lens, sel.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (pairs) BTRY(hipMemcpyAsync(pairs, d_lists, sel.size() * (size_t)pair_stride * 8, hipMemcpyDeviceToHost, ctx->stream));
+  BTRY(hipStreamSynchronize(ctx->stream));
+  BTRY(hipEventElapsedTime(&b->enum_search_ms, evs[0], evs[1]));
+  BTRY(hipEventElapsedTime(&b->enum_unroll_ms, evs[2], evs[3]));
+#undef BTRY
+  cleanup();
+  return worst;
+}
+
+extern "C" int aln_batch_last_enum_ms(aln_batch* b, float* search_ms, float* unroll_ms) {
+  if (!b) return ALN_E_ARG;
+  if (search_ms) *search_ms = b->enum_search_ms;
+  if (unroll_ms) *unroll_ms = b->enum_unroll_ms;
   return ALN_OK;
 }

@@ -204,6 +204,23 @@ int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* noa, const ui
                         aln_alignment* out, int32_t max_alignments,
                         int32_t* pairs, int64_t pairs_capacity, int32_t* n_out);
 
+/* The same enumeration for EVERY pair of the resident batch in one launch (BASELINE config 4: top-K near-optimal
+ * tracebacks per pair from the GPU-resident matrices): one wave per pair walks its own search, the host runs
+ * sortSet(number_suboptimal) per pair on (score, index) keys, survivors are unrolled on the device.  Every set is
+ * seeded with the pair's Optimal alignment (noa->n_existing is ignored).
+ *   flags: SuboptFlags rows, pair p's row at flags + p * flags_stride (flags_stride 0: one shared row of max T bytes);
+ *   node_cap_per_pair / ali_cap_per_pair: trie nodes / alignments one pair may create before ALN_E_OVERFLOW
+ *   (0 = 1 Mi nodes / 64 Ki alignments);  K: slots per pair in the outputs (>= min(number_suboptimal, set size)).
+ * Outputs (slot k of pair p at index p*K + k, set order): n_out[p] = set size after sortSet, scores, lengths,
+ * pairs (NULL = not wanted) as (q,t) int32 at (p*K + k) * pair_stride * 2, status[p] = 0 / ALN_E_STARTPAIR /
+ * ALN_E_OVERFLOW.  Returns the worst per-pair status. */
+int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const uint8_t* flags, int32_t flags_stride,
+                            uint32_t node_cap_per_pair, uint32_t ali_cap_per_pair, int32_t K,
+                            int32_t* n_out, float* scores, int32_t* lengths, int32_t* pairs, int32_t pair_stride,
+                            int32_t* status);
+/* Milliseconds the device spent in the search kernel / the unroll kernel of the last aln_batch_enumerate_all. */
+int aln_batch_last_enum_ms(aln_batch* b, float* search_ms, float* unroll_ms);
+
 /* ---- all-vs-all scoring without planes (BASELINE config 5) ------------------------------------ */
 /* The score Optimal(local) reports (find_max, optimal.h:90-93,108-124) for queries[q_begin..q_end) against EVERY
  * template: scores[(q - q_begin) * templates->n_seqs + t].  Replaces that many DPMatrix(q, t, AASubstitutionEval, fwd,

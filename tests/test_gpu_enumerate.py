@@ -104,3 +104,53 @@ def test_enumeration_user_limit_and_overflow(blosum62):
         b.enumerate(0, "ucw", 100000, 0.2, max_alignments=2)
     assert ei.value.code == aln_amd.E_OVERFLOW
     b.close()
+
+
+@pytest.mark.parametrize("kind", ["cw", "ucw"])
+def test_batched_enumeration_matches_oracle(kind, blosum62):
+    """aln_batch_enumerate_all (BASELINE config 4 form): every pair of a ragged resident batch in ONE launch, per-pair
+    SuboptFlags rows; set size, order, score bits and pair lists against the oracle, and against the one-pair entry."""
+    alpha, table = blosum62
+    lens = [9, 24, 57, 64, 90, 130, 33, 71]
+    pairs = [homolog_pair(63000 + n, ln, sub_rate=0.2, indel=3) for n, ln in enumerate(lens)]
+    maxT = max(len(t) for _, t in pairs) + 2
+    nsub, delta = 20, (0.05 if kind == "cw" else 0.02)
+    for mode, (gi, ge) in ((3, (11, 1)), (1, (11, 1)), (4, (4.73, 0.34))):
+        b = aln_amd.Batch(gpu_util.ctx(), [p[0] for p in pairs], [p[1] for p in pairs])
+        b.dp_submatrix(alpha, table, mode, gi, ge)
+        flags = np.zeros((len(pairs), maxT), dtype=np.uint8)
+        for p, (q, t) in enumerate(pairs):
+            flags[p, :len(t) + 2] = orc.make_subopt_regions(len(t) + 2, 1 + p % 5)
+        n_out, scores, lengths, lists, status = b.enumerate_all(kind, nsub, delta, flags, K=nsub + 2, node_cap=1 << 22, ali_cap=1 << 17)
+        assert (status == 0).all()
+        for p, (q, t) in enumerate(pairs):
+            S = orc.sim_submatrix(q, t, alpha, table)
+            gap = orc.Gap(mode, gi, ge)
+            rc, D0, PQ0, PT0 = orc.dp_build(S, gap)
+            rc2, sc, pl = orc.optimal(D0, PQ0, PT0, mode == 3)
+            s = orc.AliSet()
+            s.push(pl, sc)
+            orc.enumerate_noa(kind, D0, PQ0, PT0, S, gap, flags[p, :len(t) + 2], nsub, delta, s)
+            assert n_out[p] == len(s), (kind, mode, p, n_out[p], len(s))
+            one = b.enumerate(p, kind, nsub, delta, flags[p, :len(t) + 2], max_alignments=nsub + 2)
+            for k in range(len(s)):
+                r = s.get(k)
+                assert scores[p, k].view(np.uint32) == r["score"].view(np.uint32), (kind, mode, p, k)
+                assert np.array_equal(lists[p, k, :lengths[p, k]], r["pairs"]), (kind, mode, p, k)
+                assert np.array_equal(one[k]["pairs"], r["pairs"])
+        b.close()
+
+
+def test_batched_enumeration_overflow_is_per_pair(blosum62):
+    """A pool that is too small for one pair flags only that pair (status ALN_E_OVERFLOW); the others are complete."""
+    alpha, table = blosum62
+    pairs = [homolog_pair(64000, 12), homolog_pair(64001, 120, sub_rate=0.25, indel=3)]
+    b = aln_amd.Batch(gpu_util.ctx(), [p[0] for p in pairs], [p[1] for p in pairs])
+    b.dp_submatrix(alpha, table, 1, 11, 1)
+    n_out, scores, lengths, lists, status = b.enumerate_all("ucw", 50, 0.2, None, K=52, node_cap=200, raise_on_overflow=False)
+    assert status[0] == 0 and status[1] == aln_amd.E_OVERFLOW
+    one = b.enumerate(0, "ucw", 50, 0.2, max_alignments=52)
+    assert n_out[0] == len(one)
+    for k, g in enumerate(one):
+        assert np.array_equal(lists[0, k, :lengths[0, k]], g["pairs"])
+    b.close()

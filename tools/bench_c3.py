@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""BASELINE config 3 shape on ONE GPU: n pairs of L x L synthetic HMAP profiles, Hmap2Eval on the device
+(similarity + z-normalisation), exact-order DP with min(t[t1],t[t2]) gaps, Optimal traceback.
+usage: bench_c3.py [n_pairs] [L] [mode]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "alignment-algos_amd"))
+import aln_amd  # noqa: E402
+from aln_amd.synth import random_profile  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    L = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+    mode = int(sys.argv[3]) if len(sys.argv) > 3 else aln_amd.GLOBAL
+    qps = [random_profile(3000 + p, L) for p in range(n)]
+    tps = [random_profile(4000 + p, L) for p in range(n)]
+    qpool = {k: np.concatenate([p[k] for p in qps]) for k in ("aa", "sse", "conf")}
+    tpool = {k: np.concatenate([p[k] for p in tps]) for k in ("aa", "sse", "conf")}
+    ctx = aln_amd.Context(0)
+    b = aln_amd.Batch(ctx, ["A" * L] * n, ["A" * L] * n)
+    t0 = time.perf_counter()
+    b.dp_hmap2(qpool, tpool, mode, 4.73, 0.34, 0.5, 1.0, 0.12)
+    ctx.synchronize()
+    t1 = time.perf_counter()
+    scores, lists, status = b.optimal()
+    t2 = time.perf_counter()
+    dp_ms = b.last_dp_ms()
+    inner = n * (L + 2) ** 2 * (2 * L + 4) / 2.0
+    print("config3 %d pairs %dx%d mode %d: sim+dp %.3f s (DP kernel %.1f ms), traceback %.3f s; %.3f GCUPS, %.1f G inner-k evals/s; %s; score[0]=%.4f len=%d"
+          % (n, L, L, mode, t1 - t0, dp_ms, t2 - t1, n * L * L / (t1 - t0) / 1e9, inner / (dp_ms * 1e-3) / 1e9, b.kernel_name(), scores[0], len(lists[0])))
+
+
+if __name__ == "__main__":
+    main()
