@@ -145,7 +145,7 @@ void aln_batch_destroy(aln_batch* b) {
   if (!b) return;
   hipFree(b->d_pairs); hipFree(b->d_qcodes); hipFree(b->d_tcodes); hipFree(b->d_H); hipFree(b->d_P); hipFree(b->d_S);
   hipFree(b->d_res); hipFree(b->d_table32); hipFree(b->d_tablef); hipFree(b->d_tgi); hipFree(b->d_tge);
-  hipFree(b->d_path); hipFree(b->d_bounds);
+  hipFree(b->d_path); hipFree(b->d_bounds); hipFree(b->d_xscratch);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
   delete b;

@@ -76,6 +76,7 @@ struct aln_batch {
   int32_t* d_path;                             // traceback output, n_pairs x path_stride x 2
   int32_t path_stride;
   int32_t* d_bounds;
+  float* d_xscratch = nullptr; size_t xscratch_floats = 0;   // far-insertion scratch of dp_exact_blocked
   // state of the last dp
   bool have_dp, have_sub;
   int32_t sim_kind, direction, algo, bug_b4;
@@ -115,6 +116,9 @@ int launch_dp_corner(aln_batch* b);
 int launch_traceback(aln_batch* b, bool subali);
 // dp_exact.hip
 int launch_dp_exact(aln_batch* b);
+// dp_exact_blocked.hip
+bool dp_exact_blocked_legal(const aln_batch* b);
+int launch_dp_exact_blocked(aln_batch* b);
 // sim_hmap2.hip
 int launch_sim_hmap2(aln_batch* b, const aln_sim* sim);
 

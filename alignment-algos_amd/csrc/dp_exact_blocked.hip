@@ -1,0 +1,420 @@
+// dp_exact_blocked.hip — the exact-order O(n^3) DP of dp_exact.hip, restructured for gfx950 VALU throughput.
+//
+// Same results, bit for bit, as the literal builders of the reference (dpmatrix.h:356-1030): every candidate is
+//   s = D[pred]; s -= gap; s += S[i][j]; s = max(0,s) (local); if (s > opt_s) take it
+// in the order match, deletions (k ascending), insertions (k ascending).  What makes the literal loop slow is that the
+// add of S, the clip and the compare-and-select sit inside the k loops.  They do not have to:
+//
+//   * fp32 rounding and the clip are monotone, so  max_k clip(fl(fl(D_k - g_k) + S)) = clip(fl(max_k fl(D_k - g_k) + S)):
+//     the scans only need d_k = D_k - g_k (one rounded subtract, exactly the reference's `s -= gap`) and a running max;
+//   * the winning k ("first strictly greater") is the first k whose literal s_k equals that maximum.  The scans
+//     remember, per cell, the first CHUNK of k that attains max d (and the best d of all earlier chunks, `e`); only the
+//     cell whose winner is a gap re-walks that one chunk literally (or everything before it when fl(e + S) rounds to
+//     the same score — a rounding tie, rare).
+//
+// Deletion scan (row a-1 -> row a; gap = min(t[k],t[b]) coefficients, hmap2_eval.h:41-67, or constants,
+// aasubalib.h:27-51): a thread owns NS columns b = 1 + tid + 256 j and walks k once for all of them, so one broadcast
+// LDS read of (D[a-1][k], tgi[k], tge[k]) feeds up to NS x (min, min, mul, add, sub, max) — 7 VALU ops per candidate
+// against ~12 + an LDS read in the literal form.
+//
+// Insertion scan (column b-1, rows k < a-1; coefficients depend on b only): rows are processed in blocks of 16.  For a
+// block starting at a0 the candidates k <= a0-2 ("far") are evaluated for all 16 rows of the block at once: each
+// D[k][b-1] is loaded ONCE per block and the gap values G_b(n), n = a-k-2, form a window that slides by one per k
+// (one new mul+add per k, 16 x (sub, max)) — 2.2 ops per candidate and 16x fewer loads than a per-row column walk.
+// Results (max, e, chunk) wait in a per-workgroup scratch.  The <= 15 "near" candidates (rows of the current block) are
+// evaluated literally per cell.
+//
+// One workgroup (256 threads) per pair, rows in order, one barrier per row.  Frames (reverse builds, sub-rectangles) as
+// in dp_exact.hip: per-position arrays are staged in LDS in frame order, only plane addresses see real coordinates.
+#include "aln_device.h"
+
+namespace aln {
+
+constexpr int kBT = 256;       // threads per pair
+constexpr int kBR = 16;        // rows per block = window of the far-insertion scan = its chunk size
+constexpr int kBC = 32;        // deletion-scan chunk
+constexpr int kBPad = 64;
+
+__device__ __forceinline__ float vmaxf(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vminf(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// loads served by L2 (the planes are written by other threads of this workgroup; L1 lines may predate those writes)
+__device__ __forceinline__ float aload(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int aloadi(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int NS>
+struct ScanState {
+  float gib[NS], geb[NS];   // this column's own coefficients (TPOS) — unused for constant gaps
+  float fd[NS];             // (float)(b - k - 2) for the current k
+  float cm[NS], m[NS], e[NS];
+  int cidx[NS];
+};
+
+// k in [k0, k1) (both multiples of kBC), slots JJ..NS-1 active; MASK: slot JJ is in its triangular tail (fd < 0 = beyond b-2)
+template <int JJ, int NS, bool TPOS, bool MASK>
+__device__ __forceinline__ void scan_range(ScanState<NS>& s, const float* __restrict__ prev, const float2* __restrict__ tg, int k0,
+                                           int k1, float gi_c, float ge_c) {
+  const float ninf = -__builtin_inff();
+  for (int kc = k0; kc < k1; kc += kBC) {
+#pragma unroll
+    for (int u4 = 0; u4 < kBC; u4 += 4) {
+      const float4 p4 = *reinterpret_cast<const float4*>(prev + kc + u4);
+      float4 ga = {0.f, 0.f, 0.f, 0.f}, gb = {0.f, 0.f, 0.f, 0.f};
+      if (TPOS) {
+        ga = *reinterpret_cast<const float4*>(tg + kc + u4);
+        gb = *reinterpret_cast<const float4*>(tg + kc + u4 + 2);
+      }
+      const float pk[4] = {p4.x, p4.y, p4.z, p4.w};
+      const float gik[4] = {ga.x, ga.z, gb.x, gb.z};
+      const float gek[4] = {ga.y, ga.w, gb.y, gb.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int j = JJ; j < NS; ++j) {
+          const float gi = TPOS ? vminf(gik[u], s.gib[j]) : gi_c;
+          const float ge = TPOS ? vminf(gek[u], s.geb[j]) : ge_c;
+          const float g = gi + ge * s.fd[j];
+          float d = pk[u] - g;
+          if (MASK && j == JJ) d = (s.fd[j] >= 0.f) ? d : ninf;
+          s.cm[j] = vmaxf(s.cm[j], d);
+          s.fd[j] -= 1.0f;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = JJ; j < NS; ++j) {
+      const bool up = s.cm[j] > s.m[j];
+      s.e[j] = up ? s.m[j] : s.e[j];
+      s.cidx[j] = up ? kc : s.cidx[j];
+      s.m[j] = up ? s.cm[j] : s.m[j];
+      s.cm[j] = ninf;
+    }
+  }
+}
+
+// the whole deletion scan of one row for this wave: slot jj's columns are B_jj + lane, B_jj = 1 + 64 w + 256 jj
+template <int JJ, int NS, bool TPOS>
+__device__ __forceinline__ void scan_all(ScanState<NS>& s, const float* prev, const float2* tg, int wave, int kbeg, int nslots,
+                                         float gi_c, float ge_c) {
+  if constexpr (JJ < NS) {
+    if (JJ < nslots) {
+      const int tail = 64 * wave + 256 * JJ;          // = B_JJ - 1: first k that is not a candidate of lane 0
+      scan_range<JJ, NS, TPOS, false>(s, prev, tg, kbeg, tail, gi_c, ge_c);
+      scan_range<JJ, NS, TPOS, true>(s, prev, tg, tail, tail + 64, gi_c, ge_c);
+      scan_all<JJ + 1, NS, TPOS>(s, prev, tg, wave, tail + 64, nslots, gi_c, ge_c);
+    }
+  }
+}
+
+template <int NS, bool TPOS, bool LOCAL>
+__global__ __launch_bounds__(kBT, 2) void dp_exact_blocked_kernel(const PairDesc* __restrict__ pairs, EvalDev proto,
+                                                                   const uint8_t* __restrict__ qcodes, const uint8_t* __restrict__ tcodes,
+                                                                   const float* __restrict__ tgi, const float* __restrict__ tge,
+                                                                   float* __restrict__ Hbase, uint32_t* __restrict__ Pbase,
+                                                                   const float* __restrict__ Sbase, PairResult* __restrict__ res, int rev,
+                                                                   float* __restrict__ scratch_base) {
+  constexpr int PT = NS * 256 + kBPad;                 // LDS row pitch: every k the scans can touch
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* rowbuf0 = lds;                                // D[a-1][.] / D[a][.] in frame order, double-buffered
+  float* rowbuf1 = lds + PT;
+  float2* tg = reinterpret_cast<float2*>(lds + 2 * PT);   // (tgi, tge) in frame order
+  float* sres_m = lds + 4 * PT;                        // deletion-scan results of this thread's NS cells (own words only)
+  float* sres_e = sres_m + NS * kBT;
+  int* sres_c = reinterpret_cast<int*>(sres_e + NS * kBT);
+  __shared__ float red_v[kBT / 64];
+  __shared__ uint32_t red_p[kBT / 64];
+  const float ninf = -__builtin_inff();
+
+  const PairDesc pd = pairs[blockIdx.x];
+  EvalDev e = proto;
+  e.Q = pd.Q; e.T = pd.T; e.ld = pd.ld;
+  e.qc = qcodes ? qcodes + pd.q_off : nullptr;
+  e.tc = tcodes ? tcodes + pd.t_off : nullptr;
+  e.tgi = tgi ? tgi + pd.t_off : nullptr;
+  e.tge = tge ? tge + pd.t_off : nullptr;
+  e.S = Sbase ? Sbase + pd.plane_off : nullptr;
+  float* __restrict__ H = Hbase + pd.plane_off;
+  uint32_t* __restrict__ P = Pbase + pd.plane_off;
+  const int ld = pd.ld;
+  const Frame f = {pd.q0, pd.q1, pd.t0, pd.t1, rev};
+  const int nQ = f.nQ(), nT = f.nT();
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const float gi_c = e.gi, ge_c = e.ge;
+  // far-insertion results of the current block: planes m / e / chunk, [kBR][PT] each
+  float* scr_m = scratch_base + (size_t)blockIdx.x * 3 * kBR * PT;
+  float* scr_e = scr_m + kBR * PT;
+  int* scr_c = reinterpret_cast<int*>(scr_e + kBR * PT);
+
+  float lmax = 0.f; uint32_t lpos = 0xFFFFFFFFu;
+  const uint32_t origin = pack_ptr(f.rq(0), f.rt(0));
+
+  if (nQ >= 2 && nT >= 2) {
+    // ---- stage per-position arrays in frame order; pads read as "no candidate" --------------------------------
+    for (int x = tid; x < PT; x += kBT) {
+      rowbuf0[x] = ninf; rowbuf1[x] = ninf;
+      float2 v = {0.f, 0.f};
+      if (TPOS && x <= nT) { const int pos = f.rt(x); v.x = e.tgi[pos]; v.y = e.tge[pos]; }
+      tg[x] = v;
+    }
+    __syncthreads();
+    // slots this WAVE has to scan (lane 0's column decides; later lanes of a partly valid slot are masked at the store)
+    int nslots = 0;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) if (1 + 64 * wave + 256 * j <= nT - 1) nslots = j + 1;
+
+    for (int a0 = 1; a0 <= nQ - 1; a0 += kBR) {
+      // ================= far insertions of rows a0 .. a0+15: candidates k = 1 .. a0-2 ============================
+      if (a0 >= 3) {
+#pragma unroll 1
+        for (int j = 0; j < NS; ++j) {
+          if (1 + 64 * wave + 256 * j > nT - 1) break;
+          const int bc = 1 + tid + 256 * j;
+          const bool bv = bc <= nT - 1;
+          const int b = (bc < 2 || !bv) ? 2 : bc;     // b = 1 has no insertions; invalid lanes compute a dummy column
+          float gi = gi_c, ge = ge_c;                 // insertion coefficients of column b: min over (b-1, b)  (hmap2_eval.h:69-95)
+          if (TPOS) { const float2 t0 = tg[b - 1], t1 = tg[b]; gi = fminr(t0.x, t1.x); ge = fminr(t0.y, t1.y); }
+          const size_t colb = (size_t)f.rt(b - 1);
+          float W[kBR], cm[kBR], m[kBR], ee[kBR]; int cc[kBR];
+          float fn = (float)(a0 - 2);                 // n of (row a0, k = 0); row a0+r adds r
+#pragma unroll
+          for (int i = 0; i < kBR; ++i) { W[i] = gi + ge * (fn + (float)i); cm[i] = ninf; m[i] = ninf; ee[i] = ninf; cc[i] = 0; }
+          for (int kc = 0; kc <= a0 - 2; kc += kBR) {
+            float x[kBR];
+#pragma unroll
+            for (int u = 0; u < kBR; ++u) {
+              const int k = kc + u;
+              x[u] = (k >= 1 && k <= a0 - 2) ? aload(&H[(size_t)f.rq(k) * ld + colb]) : ninf;
+            }
+#pragma unroll
+            for (int u = 0; u < kBR; ++u) {
+#pragma unroll
+              for (int r = 0; r < kBR; ++r) cm[r] = vmaxf(cm[r], x[u] - W[(r - u) & (kBR - 1)]);
+              fn -= 1.0f;
+              W[kBR - 1 - u] = gi + ge * fn;          // G(n0 - 1) for the next k
+            }
+#pragma unroll
+            for (int r = 0; r < kBR; ++r) {
+              const bool up = cm[r] > m[r];
+              ee[r] = up ? m[r] : ee[r];
+              cc[r] = up ? kc : cc[r];
+              m[r] = up ? cm[r] : m[r];
+              cm[r] = ninf;
+            }
+          }
+          if (bv && bc >= 2) {
+#pragma unroll
+            for (int r = 0; r < kBR; ++r) { scr_m[r * PT + bc] = m[r]; scr_e[r * PT + bc] = ee[r]; scr_c[r * PT + bc] = cc[r]; }
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(0);   // own scratch words are read back by this same thread through L2
+      }
+
+      // ================= the rows of the block ===================================================================
+      const int a_end = (a0 + kBR - 1 < nQ - 1) ? a0 + kBR - 1 : nQ - 1;
+      for (int a = a0; a <= a_end; ++a) {
+        const int i = f.rq(a);
+        const float* prev = (a & 1) ? rowbuf0 : rowbuf1;       // row a-1
+        float* cur = (a & 1) ? rowbuf1 : rowbuf0;
+        const int r = a - a0;
+        if (a == 1) {
+          // ---- first row: dpmatrix.h:409-418 -------------------------------------------------------------------
+#pragma unroll 1
+          for (int j = 0; j < NS; ++j) {
+            const int b = 1 + tid + 256 * j;
+            if (b > nT - 1) break;
+            const int jj = f.rt(b);
+            const float sim = dev_sim(e, i, jj);
+            float sv = 0.f;
+            if (b > 1) sv -= frame_del(e, f, 0, b);
+            sv += sim;
+            const float opt = clip0(sv, LOCAL);
+            H[(size_t)i * ld + jj] = opt; P[(size_t)i * ld + jj] = origin;
+            cur[b] = opt;
+            if (opt > lmax) { lmax = opt; lpos = ((uint32_t)a << 16) | (uint32_t)b; }
+          }
+        } else {
+          // ---- deletion scan over row a-1 ----------------------------------------------------------------------
+          ScanState<NS> s;
+#pragma unroll
+          for (int j = 0; j < NS; ++j) {
+            const int bc = 1 + tid + 256 * j;
+            if (TPOS) { const float2 t = tg[bc]; s.gib[j] = t.x; s.geb[j] = t.y; } else { s.gib[j] = 0.f; s.geb[j] = 0.f; }
+            s.fd[j] = (float)(bc - 2);
+            s.cm[j] = ninf; s.m[j] = ninf; s.e[j] = ninf; s.cidx[j] = 0;
+          }
+          scan_all<0, NS, TPOS>(s, prev, tg, wave, 0, nslots, gi_c, ge_c);
+#pragma unroll
+          for (int j = 0; j < NS; ++j) { sres_m[j * kBT + tid] = s.m[j]; sres_e[j * kBT + tid] = s.e[j]; sres_c[j * kBT + tid] = s.cidx[j]; }
+          // ---- per cell: match, best deletion, best insertion, pointer ----------------------------------------
+#pragma unroll 1
+          for (int j = 0; j < NS; ++j) {
+            if (1 + 64 * wave + 256 * j > nT - 1) break;
+            const int b = 1 + tid + 256 * j;
+            const bool valid = b <= nT - 1;
+            const float dm = sres_m[j * kBT + tid], de = sres_e[j * kBT + tid];
+            const int dc = sres_c[j * kBT + tid];
+            const int bb = valid ? b : 1;                     // invalid lanes walk a harmless cell and store nothing
+            const int jj = f.rt(bb);
+            const float sim = dev_sim(e, i, jj);
+            float opt; uint32_t optp;
+            if (bb == 1) {                                     // dpmatrix.h:421-426
+              float sv = 0.f;
+              sv -= frame_ins(e, f, 0, a, 0, 1);
+              sv += sim;
+              opt = clip0(sv, LOCAL); optp = origin;
+            } else {
+              const size_t colb = (size_t)f.rt(bb - 1);
+              // near insertion candidates k = kn0 .. a-2 (rows of this block, and the row just before it)
+              const int kn0 = (a0 - 1 > 1) ? a0 - 1 : 1;
+              float xn[kBR];
+#pragma unroll
+              for (int u = 0; u < kBR; ++u) xn[u] = (kn0 + u <= a - 2) ? aload(&H[(size_t)f.rq(kn0 + u) * ld + colb]) : ninf;
+              float mf = ninf, ef = ninf; int cf = 0;
+              if (a0 >= 3) { mf = aload(&scr_m[r * PT + bb]); ef = aload(&scr_e[r * PT + bb]); cf = aloadi(&scr_c[r * PT + bb]); }
+              opt = clip0(prev[bb - 1] + sim, LOCAL);          // match, :447-451
+              int cat = 0;
+              const float sd = clip0(dm + sim, LOCAL);
+              if (sd > opt) { opt = sd; cat = 1; }
+              const float sfar = clip0(mf + sim, LOCAL);
+              float snear = ninf; int knear = 0;
+              float gi = gi_c, ge = ge_c;
+              if (TPOS) { const float2 t0 = tg[bb - 1], t1 = tg[bb]; gi = fminr(t0.x, t1.x); ge = fminr(t0.y, t1.y); }
+#pragma unroll
+              for (int u = 0; u < kBR; ++u) {
+                if (kn0 + u <= a - 2) {
+                  float sv = xn[u];
+                  sv -= gi + ge * (float)(a - (kn0 + u) - 2);
+                  sv += sim;
+                  sv = clip0(sv, LOCAL);
+                  if (sv > snear) { snear = sv; knear = kn0 + u; }
+                }
+              }
+              const float si = (snear > sfar) ? snear : sfar;
+              if (si > opt) { opt = si; cat = (snear > sfar) ? 3 : 2; }
+              int oa = a - 1, ob = bb - 1;
+              if (cat == 1) {
+                // first deletion k whose literal score is the maximum: inside chunk cidx unless an earlier chunk ties after rounding
+                const bool amb = clip0(de + sim, LOCAL) == opt;
+                int k = amb ? 1 : (dc > 1 ? dc : 1);
+                const float gbi = TPOS ? tg[bb].x : 0.f, gbe = TPOS ? tg[bb].y : 0.f;
+                for (; k < bb - 2; ++k) {
+                  const float2 tk = tg[k];
+                  const float g = (TPOS ? fminr(tk.x, gbi) : gi_c) + (TPOS ? fminr(tk.y, gbe) : ge_c) * (float)(bb - k - 2);
+                  float sv = prev[k];
+                  sv -= g;
+                  sv += sim;
+                  sv = clip0(sv, LOCAL);
+                  if (sv == opt) break;
+                }
+                oa = a - 1; ob = k;                           // k == bb-2 is the last candidate: taken if nothing earlier matched
+              } else if (cat == 2) {
+                const bool amb = clip0(ef + sim, LOCAL) == opt;
+                int k = amb ? 1 : (cf > 1 ? cf : 1);
+                for (; k < a0 - 2; ++k) {
+                  float sv = aload(&H[(size_t)f.rq(k) * ld + colb]);
+                  sv -= gi + ge * (float)(a - k - 2);
+                  sv += sim;
+                  sv = clip0(sv, LOCAL);
+                  if (sv == opt) break;
+                }
+                oa = k; ob = bb - 1;
+              } else if (cat == 3) {
+                oa = knear; ob = bb - 1;
+              }
+              optp = pack_ptr(f.rq(oa), f.rt(ob));
+            }
+            if (valid) {
+              H[(size_t)i * ld + jj] = opt; P[(size_t)i * ld + jj] = optp;
+              cur[b] = opt;
+              if (opt > lmax) { lmax = opt; lpos = ((uint32_t)a << 16) | (uint32_t)b; }
+            }
+          }
+        }
+        __threadfence_block();
+        __syncthreads();        // row a complete: in LDS for the next row's scans, in L2 for later column walks
+      }
+    }
+  }
+  // find_max partial in frame coordinates (first in frame row-major order among the maxima)
+  float m = lmax; uint32_t p = lpos;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    float om = __shfl_xor(m, o); uint32_t op = (uint32_t)__shfl_xor((int)p, o);
+    bool take = om > m || (om == m && op < p);
+    m = take ? om : m; p = take ? op : p;
+  }
+  if ((threadIdx.x & 63) == 0) { red_v[threadIdx.x >> 6] = m; red_p[threadIdx.x >> 6] = p; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kBT / 64; ++w) {
+      bool take = red_v[w] > m || (red_v[w] == m && red_p[w] < p);
+      if (take) { m = red_v[w]; p = red_p[w]; }
+    }
+    uint32_t rp = 0xFFFFFFFFu;
+    if (p != 0xFFFFFFFFu && m > 0.f) rp = ((uint32_t)f.rq((int)(p >> 16)) << 16) | (uint32_t)f.rt((int)(p & 0xFFFFu));
+    res[blockIdx.x].part_max = m;
+    res[blockIdx.x].part_pos = rp;
+  }
+}
+
+template <int NS>
+static int launch_ns(aln_batch* b, const EvalDev& proto, bool tpos, bool sub, float* scratch) {
+  aln_ctx* ctx = b->ctx;
+  constexpr int PT = NS * 256 + kBPad;
+  const size_t lds = ((size_t)PT * 4 + (size_t)3 * NS * kBT) * sizeof(float);
+  const int rev = (int)(b->direction == ALN_REV);
+#define ALN_XLAUNCH(TP, LC)                                                                                                   \
+  hipLaunchKernelGGL((dp_exact_blocked_kernel<NS, TP, LC>), dim3(b->n_pairs), dim3(kBT), lds, ctx->stream, b->d_pairs, proto,   \
+                     sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr,                      \
+                     tpos ? b->d_tge : nullptr, b->d_H, b->d_P, sub ? nullptr : b->d_S, b->d_res, rev, scratch)
+  if (tpos) { if (b->islocal) ALN_XLAUNCH(true, true); else ALN_XLAUNCH(true, false); }
+  else { if (b->islocal) ALN_XLAUNCH(false, true); else ALN_XLAUNCH(false, false); }
+#undef ALN_XLAUNCH
+  ALN_HIP_CHECK(ctx, hipGetLastError());
+  return ALN_OK;
+}
+
+// bytes of scratch one pair needs for a given slot count
+static size_t blocked_scratch_floats(int ns) { return (size_t)3 * kBR * (ns * 256 + kBPad); }
+
+bool dp_exact_blocked_legal(const aln_batch* b) {
+  int mx = 0;
+  for (const PairDesc& d : b->h_pairs) { const int nT = d.t1 - d.t0; if (nT - 1 > mx) mx = nT - 1; }
+  return mx <= 8 * 256;
+}
+
+int launch_dp_exact_blocked(aln_batch* b) {
+  aln_ctx* ctx = b->ctx;
+  int mx = 1;
+  for (const PairDesc& d : b->h_pairs) { const int nT = d.t1 - d.t0; if (nT - 1 > mx) mx = nT - 1; }
+  const int ns = mx <= 256 ? 1 : mx <= 512 ? 2 : mx <= 1024 ? 4 : 8;
+  const size_t need = blocked_scratch_floats(ns) * (size_t)b->n_pairs;
+  if (b->xscratch_floats < need) {
+    if (b->d_xscratch) { ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); hipFree(b->d_xscratch); b->d_xscratch = nullptr; b->xscratch_floats = 0; }
+    if (hipMalloc((void**)&b->d_xscratch, need * 4) != hipSuccess) { ctx->last_error = "hipMalloc (far-insertion scratch)"; return ALN_E_NOMEM; }
+    b->xscratch_floats = need;
+  }
+  // untouched cells read score 0 / pointer (-1,-1) (dpmatrix.cpp:17-25): the kernel only writes computed cells
+  ALN_HIP_CHECK(ctx, hipMemsetAsync(b->d_H, 0, (size_t)b->plane_elems * 4, ctx->stream));
+  ALN_HIP_CHECK(ctx, hipMemsetAsync(b->d_P, 0xFF, (size_t)b->plane_elems * 4, ctx->stream));
+  EvalDev proto = {};
+  proto.model = b->gapdev.model;
+  proto.align_type = b->gapdev.align_type;
+  proto.gi = b->gapdev.gi; proto.ge = b->gapdev.ge;
+  proto.sim_kind = (b->sim_kind == ALN_SIM_SUBMATRIX) ? ALN_SIM_SUBMATRIX : ALN_SIM_MATRIX;
+  proto.tablef = b->d_tablef;
+  const bool sub = b->sim_kind == ALN_SIM_SUBMATRIX;
+  const bool tpos = b->gapdev.model == ALN_GAP_AFFINE_TPOS_MIN;
+  int rc;
+  switch (ns) {
+    case 1: rc = launch_ns<1>(b, proto, tpos, sub, b->d_xscratch); break;
+    case 2: rc = launch_ns<2>(b, proto, tpos, sub, b->d_xscratch); break;
+    case 4: rc = launch_ns<4>(b, proto, tpos, sub, b->d_xscratch); break;
+    default: rc = launch_ns<8>(b, proto, tpos, sub, b->d_xscratch); break;
+  }
+  if (rc) return rc;
+  b->kernel_name = std::string("dp_exact_blocked_kernel<") + (tpos ? "tpos," : "const,") + (b->islocal ? "local" : "global") +
+                   (b->direction == ALN_REV ? ",rev>" : ",fwd>");
+  return ALN_OK;
+}
+
+}  // namespace aln

@@ -284,3 +284,50 @@ def test_full_size_properties(blosum62):
                     s -= 11 + (gap - 1)
         assert s == scores[p], (p, s, scores[p])
     b.close()
+
+
+@pytest.mark.parametrize("direction", ["fwd", "rev"])
+def test_blocked_exact_kernel_long_rows(direction, blosum62):
+    """dp_exact_blocked (max-first scans, chunk re-walks, 16-row far-insertion window) on templates that need 2, 4 and 8
+    column slots per thread and several row blocks: integer gaps forced through it (many exact ties -> the "first k"
+    and rounding-tie paths), fractional gaps, and profile-style fractional planes with min(t[t1],t[t2]) gaps."""
+    alpha, table = blosum62
+    d = DIRS[direction]
+    od = orc.FWD if direction == "fwd" else orc.REV
+    shapes = [(70, 300), (40, 700), (350, 90), (45, 1100), (60, 2040)]
+    pairs = []
+    for n, (ql, tl) in enumerate(shapes):
+        q, t = homolog_pair(81000 + n, max(ql, tl), sub_rate=0.3, indel=5)
+        pairs.append((q[:ql], t[:tl]))
+    for mode, gi, ge, algo in ((3, 11, 1, aln_amd.DP_EXACT), (1, 4.73, 0.34, aln_amd.DP_AUTO), (4, 1, 1, aln_amd.DP_EXACT)):
+        b = aln_amd.Batch(gpu_util.ctx(), [p[0] for p in pairs], [p[1] for p in pairs])
+        b.dp_submatrix(alpha, table, mode, gi, ge, d, algo, bug_b4=True)
+        assert "dp_exact_blocked" in b.kernel_name()
+        for p, (q, t) in enumerate(pairs):
+            S = orc.sim_submatrix(q, t, alpha, table)
+            rc, D0, PQ0, PT0 = orc.dp_build(S, orc.Gap(mode, gi, ge), od, bug_b4=True)
+            D, PQ, PT = b.get_cells(p)
+            assert np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (p, mode, gi, direction)
+            assert np.array_equal(PQ, PQ0) and np.array_equal(PT, PT0), (p, mode, gi, direction)
+        b.close()
+    # fractional planes + position-dependent gaps
+    rng = np.random.RandomState(11)
+    dims = [(50, 600), (300, 1500), (37, 2050)]
+    planes, tgis, tges = [], [], []
+    for (Q, T) in dims:
+        S = rng.normal(-0.12, 1.0, size=(Q, T)).astype(np.float32)
+        S[0, :] = 0; S[-1, :] = 0; S[:, 0] = 0; S[:, -1] = 0
+        planes.append(S)
+        pi = np.exp(rng.uniform(-0.25, 1.0, size=T)).astype(np.float32)
+        tgis.append((np.float32(4.73) * pi).astype(np.float32))
+        tges.append((np.float32(0.34) * pi).astype(np.float32))
+    for mode in (1, 3):
+        b = aln_amd.Batch(gpu_util.ctx(), ["A" * (Q - 2) for Q, T in dims], ["A" * (T - 2) for Q, T in dims])
+        b.dp_simmatrix(planes, mode, 0, 0, d, tgi=np.concatenate(tgis), tge=np.concatenate(tges))
+        assert "dp_exact_blocked" in b.kernel_name()
+        for p, S in enumerate(planes):
+            rc, D0, PQ0, PT0 = orc.dp_build(S, orc.Gap(mode, tgi=tgis[p], tge=tges[p]), od)
+            D, PQ, PT = b.get_cells(p)
+            assert np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (p, mode, direction)
+            assert np.array_equal(PQ, PQ0) and np.array_equal(PT, PT0), (p, mode, direction)
+        b.close()
