@@ -101,24 +101,49 @@ __global__ __launch_bounds__(64) void enumerate_kernel(const PairDesc* __restric
     s += HV(q0, t0);
     set_score(k0, s);
   };
-  // the pointer-following loop of opt_path (cw.h:242-272 / ucw.h:207-228); returns the cell it stopped at
+  // the pointer-following loop of opt_path (cw.h:242-272 / ucw.h:207-228); returns the cell it stopped at.
+  // 64 cells of the current diagonal are examined at once (lane l: cell (q0-l, t0-l)): the leading run of cells whose
+  // stored pointer is the match pointer is taken in one step — their trie nodes are written in parallel, their
+  // similarities are summed in path order (fp32 is not associative) — and a gap cell ends the run with one jump.
   auto walk = [&](int& q0, int& t0, int k0, bool force) {
     const bool flag = cw ? !a.flags[t0] : false;
     float sc = ld_f(&a.score[k0]);
+    uint32_t hd = ld_u(&a.head[k0]);
     while (t0 > 1 && q0 > 1 && status == 0) {
-      if (cw && !force && ((a.flags[t0] != 0) == flag)) break;   // the template's SuboptFlags bit flipped: branch point
-      prepend(k0, q0, t0);
-      sc += dev_sim(e, q0, t0);
-      const uint32_t p = load_ptr_word(Pbase, pd.plane_off, ld, q0, t0, a.ptr_mode);
-      int pq, pt;
-      decode_ptr(p, a.ptr_mode, q0, t0, pq, pt);
-      float g;
-      if (q0 - pq == 1) g = dev_deletion(e, pt, t0);
-      else g = dev_insertion(e, pq, q0, pt, t0);
-      sc -= g;
-      t0 = pt; q0 = pq;
+      const int q = q0 - lane, t = t0 - lane;
+      bool stop = !(q > 1 && t > 1);
+      if (!stop && cw && !force && ((a.flags[t] != 0) == flag)) stop = true;   // the template's SuboptFlags bit flipped: branch point
+      int pq = 0, pt = 0; float sv = 0.f, g = 0.f;
+      if (!stop) {
+        const uint32_t p = load_ptr_word(Pbase, pd.plane_off, ld, q, t, a.ptr_mode);
+        decode_ptr(p, a.ptr_mode, q, t, pq, pt);
+        sv = dev_sim(e, q, t);
+      }
+      const bool diag = !stop && pq == q - 1 && pt == t - 1;
+      const unsigned long long m_end = __ballot(!diag);
+      const int F = m_end ? __builtin_ctzll(m_end) : 64;          // first cell that is not a plain match step
+      const bool gap_cell = F < 64 && !(((__ballot(stop)) >> F) & 1ull);
+      const int n_proc = gap_cell ? F + 1 : F;
+      if (n_proc == 0) break;
+      if (n_nodes + (uint32_t)n_proc > a.node_cap) { status = ALN_E_OVERFLOW; break; }
+      if (lane < n_proc) {
+        a.node_pair[n_nodes + lane] = ((uint32_t)q << 16) | (uint32_t)t;
+        a.node_next[n_nodes + lane] = lane == 0 ? hd : n_nodes + lane - 1;
+      }
+      hd = n_nodes + n_proc - 1;
+      n_nodes += n_proc;
+      if (gap_cell && lane == F) {
+        if (q - pq == 1) g = dev_deletion(e, pt, t);
+        else g = dev_insertion(e, pq, q, pt, t);
+      }
+      for (int l = 0; l < n_proc; ++l) sc += __shfl(sv, l);       // sc += sim (then sc -= 0 for a match step), in path order
+      if (gap_cell) {
+        sc -= __shfl(g, F);
+        q0 = __shfl(pq, F); t0 = __shfl(pt, F);
+      } else { q0 -= n_proc; t0 -= n_proc; }
     }
-    set_score(k0, sc);
+    if (lane == 0) { st_u(&a.head[k0], hd); st_f(&a.score[k0], sc); }
+    sync_mem();
   };
 
   // Depth-first search with an explicit stack of branch frames.  A pending call is either
@@ -166,31 +191,39 @@ __global__ __launch_bounds__(64) void enumerate_kernel(const PairDesc* __restric
     const int ndel = t0 - 2, nins = q0 - 2;
     const int ncand = 1 + ndel + nins;
     int found = -1; float fg = 0.f; int fq = 0, ft = 0;
-    for (int base = cursor; base < ncand && found < 0; base += 64) {
-      const int idx = base + lane;
-      bool ok = false; float g = 0.f; int pq = 0, pt = 0;
-      if (idx < ncand) {
-        if (idx == 0) {                                     // match, cw.h:151-162
-          pq = q0 - 1; pt = t0 - 1;
-          const float fsc = HV(pq, pt);
-          ok = fsc + r > thr;
-        } else if (idx <= ndel) {                           // deletions i = t0-2 .. 1, cw.h:166-178
-          pq = q0 - 1; pt = t0 - 1 - idx;
-          const float fsc = HV(pq, pt);
-          g = dev_deletion(e, pt, t0);
-          ok = fsc + r - g > thr;
-        } else {                                            // insertions j = q0-2 .. 1, cw.h:182-194
-          pq = q0 - 2 - (idx - ndel - 1); pt = t0 - 1;
-          const float fsc = HV(pq, pt);
-          g = dev_insertion(e, pq, q0, pt, t0);
-          ok = fsc + r - g > thr;
+    // 4 x 64 candidates per trip: the score loads of all four groups are in flight together, the ballots keep the order
+    for (int base = cursor; base < ncand && found < 0; base += 256) {
+      bool ok[4]; float g[4]; int pq[4], pt[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = base + 64 * u + lane;
+        ok[u] = false; g[u] = 0.f; pq[u] = 0; pt[u] = 0;
+        if (idx < ncand) {
+          if (idx == 0) {                                     // match, cw.h:151-162
+            pq[u] = q0 - 1; pt[u] = t0 - 1;
+            const float fsc = HV(pq[u], pt[u]);
+            ok[u] = fsc + r > thr;
+          } else if (idx <= ndel) {                           // deletions i = t0-2 .. 1, cw.h:166-178
+            pq[u] = q0 - 1; pt[u] = t0 - 1 - idx;
+            const float fsc = HV(pq[u], pt[u]);
+            g[u] = dev_deletion(e, pt[u], t0);
+            ok[u] = fsc + r - g[u] > thr;
+          } else {                                            // insertions j = q0-2 .. 1, cw.h:182-194
+            pq[u] = q0 - 2 - (idx - ndel - 1); pt[u] = t0 - 1;
+            const float fsc = HV(pq[u], pt[u]);
+            g[u] = dev_insertion(e, pq[u], q0, pt[u], t0);
+            ok[u] = fsc + r - g[u] > thr;
+          }
         }
       }
-      const unsigned long long m = __ballot(ok);
-      if (m) {
-        const int l = __builtin_ctzll(m);
-        found = base + l;
-        fg = __shfl(g, l); fq = __shfl(pq, l); ft = __shfl(pt, l);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned long long m = __ballot(ok[u]);
+        if (m && found < 0) {
+          const int l = __builtin_ctzll(m);
+          found = base + 64 * u + l;
+          fg = __shfl(g[u], l); fq = __shfl(pq[u], l); ft = __shfl(pt[u], l);
+        }
       }
     }
     if (found < 0) {

@@ -144,16 +144,39 @@ __global__ __launch_bounds__(64) void hmap2_stats_kernel(const PairDesc* __restr
   int i0 = 1, i1 = Q - 1, j0 = 1, j1 = T - 1;
   if (i0 >= i1 || j0 >= j1) { i0 = 0; j0 = 0; i1 = Q; j1 = T; }   // hmath.h:65-66
   float sum = 0.f, sumsq = 0.f;
-  for (int i = i0; i < i1; ++i) {
-    for (int jb = j0; jb < j1; jb += 64) {
-      const int cnt = min(64, j1 - jb);
-      float v = (lane < cnt) ? S[(size_t)i * ld + jb + lane] : 0.f;
-      float sq = v * v;
-      for (int l = 0; l < cnt; ++l) {                 // the reference's order: one element at a time
-        float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l));
-        float s2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sq), l));
-        sum += x;
-        sumsq += s2;
+  // The two chains are inherently serial (fp32 sums in the reference's row-major order); what can be hidden is the
+  // memory latency: 8 x 64 elements are in flight while the previous 512 are being added.
+  const int W = j1 - j0, N = (i1 - i0) * W;
+  constexpr int kU = 8;
+  float v[kU];
+  auto fetch = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int n = base + 64 * u + lane;
+      v[u] = (n < N) ? S[(size_t)(i0 + n / W) * ld + j0 + n % W] : 0.f;
+    }
+  };
+  fetch(0);
+  for (int base = 0; base < N; base += 64 * kU) {
+    float cv[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) cv[u] = v[u];
+    if (base + 64 * kU < N) fetch(base + 64 * kU);
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const float sq = cv[u] * cv[u];
+      const int cnt = min(64, N - (base + 64 * u));
+      if (cnt == 64) {
+#pragma unroll
+        for (int l = 0; l < 64; ++l) {                  // the reference's order: one element at a time
+          sum += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cv[u]), l));
+          sumsq += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sq), l));
+        }
+      } else {
+        for (int l = 0; l < cnt; ++l) {
+          sum += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cv[u]), l));
+          sumsq += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sq), l));
+        }
       }
     }
   }
