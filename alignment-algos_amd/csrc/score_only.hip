@@ -40,6 +40,7 @@ struct ScoreArgs {
   const uint8_t* qcodes; const int64_t* qoff;   // query pool, offsets (n_q + 1)
   const uint8_t* tcodes; const int64_t* toff;   // template pool
   const int32_t* table32;                       // 32 x 32
+  const int32_t* tsel;                          // blockIdx.x -> template index (templates are launched by length class)
   float* scores;                                // rows x n_t
   int q_begin, n_t;
   int gi, ge;
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(64) void score_local_kernel(ScoreArgs a) {
   const int lane = threadIdx.x;
   for (int k = lane; k < 32 * 32; k += 64) tab[k] = a.table32[k];
   __syncthreads();
-  const int ti = blockIdx.x, qi = a.q_begin + blockIdx.y;
+  const int ti = a.tsel[blockIdx.x], qi = a.q_begin + blockIdx.y;
   const uint8_t* __restrict__ qc = a.qcodes + a.qoff[qi];
   const uint8_t* __restrict__ tc = a.tcodes + a.toff[ti];
   const int Q = (int)(a.qoff[qi + 1] - a.qoff[qi]), T = (int)(a.toff[ti + 1] - a.toff[ti]);
@@ -218,8 +219,8 @@ extern "C" int aln_score_all_vs_all(aln_ctx* ctx, const aln_seqs* queries, const
   if (rows == 0 || n_t == 0) return ALN_OK;
 
   ScoreArgs a = {};
-  uint8_t *dq = nullptr, *dt = nullptr; int64_t *dqo = nullptr, *dto = nullptr; int32_t* dtab = nullptr; float* dsc = nullptr;
-  auto cleanup = [&]() { hipFree(dq); hipFree(dt); hipFree(dqo); hipFree(dto); hipFree(dtab); hipFree(dsc); };
+  uint8_t *dq = nullptr, *dt = nullptr; int64_t *dqo = nullptr, *dto = nullptr; int32_t* dtab = nullptr; float* dsc = nullptr; int32_t* dsel = nullptr;
+  auto cleanup = [&]() { hipFree(dq); hipFree(dt); hipFree(dqo); hipFree(dto); hipFree(dtab); hipFree(dsc); hipFree(dsel); };
 #define STRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup(); return ALN_E_HIP; } } while (0)
   STRY(hipMalloc((void**)&dq, qc.size())); STRY(hipMalloc((void**)&dt, tc.size()));
   STRY(hipMalloc((void**)&dqo, (size_t)(queries->n_seqs + 1) * 8)); STRY(hipMalloc((void**)&dto, (size_t)(n_t + 1) * 8));
@@ -231,20 +232,44 @@ extern "C" int aln_score_all_vs_all(aln_ctx* ctx, const aln_seqs* queries, const
   STRY(hipMemcpyAsync(dtab, ti, sizeof ti, hipMemcpyHostToDevice, ctx->stream));
   a.qcodes = dq; a.qoff = dqo; a.tcodes = dt; a.toff = dto; a.table32 = dtab; a.scores = dsc;
   a.q_begin = q_begin; a.n_t = n_t; a.gi = (int)gi; a.ge = (int)ge;
-  const int ld = (maxT + 3) & ~3;
+  // Templates are launched by length class: a wave sweeps 256 R columns, so a template of T columns needs
+  // R = ceil(T / 256) groups; one launch per class keeps short templates from paying for the longest one.
+  std::vector<int32_t> order; std::vector<int> cls_begin(10, 0);
+  {
+    std::vector<std::vector<int32_t>> by(9);
+    for (int t = 0; t < n_t; ++t) {
+      const int T = (int)(templates->offsets[t + 1] - templates->offsets[t]);
+      by[(T + 255) / 256].push_back(t);
+    }
+    for (int r = 1; r <= 8; ++r) { cls_begin[r] = (int)order.size(); order.insert(order.end(), by[r].begin(), by[r].end()); }
+    cls_begin[9] = (int)order.size();
+  }
+  STRY(hipMalloc((void**)&dsel, (size_t)n_t * 4));
+  STRY(hipMemcpyAsync(dsel, order.data(), (size_t)n_t * 4, hipMemcpyHostToDevice, ctx->stream));
   const dim3 block(64);
   // blockIdx.y is limited to 65535: walk the query rows in slabs
   for (int r0 = 0; r0 < rows; r0 += 32768) {
     const int nr = std::min(32768, rows - r0);
-    ScoreArgs s = a;
-    s.q_begin = q_begin + r0;
-    s.scores = dsc + (size_t)r0 * n_t;
-    const dim3 grid(n_t, nr);
-    if (ld <= 256) hipLaunchKernelGGL(score_local_kernel<1>, grid, block, 0, ctx->stream, s);
-    else if (ld <= 512) hipLaunchKernelGGL(score_local_kernel<2>, grid, block, 0, ctx->stream, s);
-    else if (ld <= 1024) hipLaunchKernelGGL(score_local_kernel<4>, grid, block, 0, ctx->stream, s);
-    else hipLaunchKernelGGL(score_local_kernel<8>, grid, block, 0, ctx->stream, s);
-    STRY(hipGetLastError());
+    for (int r = 1; r <= 8; ++r) {
+      const int nc = cls_begin[r + 1] - cls_begin[r];
+      if (nc == 0) continue;
+      ScoreArgs s = a;
+      s.q_begin = q_begin + r0;
+      s.scores = dsc + (size_t)r0 * n_t;
+      s.tsel = dsel + cls_begin[r];
+      const dim3 grid(nc, nr);
+      switch (r) {
+        case 1: hipLaunchKernelGGL(score_local_kernel<1>, grid, block, 0, ctx->stream, s); break;
+        case 2: hipLaunchKernelGGL(score_local_kernel<2>, grid, block, 0, ctx->stream, s); break;
+        case 3: hipLaunchKernelGGL(score_local_kernel<3>, grid, block, 0, ctx->stream, s); break;
+        case 4: hipLaunchKernelGGL(score_local_kernel<4>, grid, block, 0, ctx->stream, s); break;
+        case 5: hipLaunchKernelGGL(score_local_kernel<5>, grid, block, 0, ctx->stream, s); break;
+        case 6: hipLaunchKernelGGL(score_local_kernel<6>, grid, block, 0, ctx->stream, s); break;
+        case 7: hipLaunchKernelGGL(score_local_kernel<7>, grid, block, 0, ctx->stream, s); break;
+        default: hipLaunchKernelGGL(score_local_kernel<8>, grid, block, 0, ctx->stream, s); break;
+      }
+      STRY(hipGetLastError());
+    }
   }
   STRY(hipMemcpyAsync(scores, dsc, (size_t)rows * n_t * 4, hipMemcpyDeviceToHost, ctx->stream));
   STRY(hipStreamSynchronize(ctx->stream));

@@ -17,6 +17,7 @@
 #include "formats.h"
 #include "noalib.h"
 #include "optimal.h"
+#include "pirio.h"
 #include "rcfile.h"
 #include "sequence.h"
 #include "sflags.h"
@@ -84,6 +85,9 @@ int main(int argc, const char** argv) {
     switch (app_params.output_format) {
       case oFASTA:
         cout << Formats::FastaOut(app_params.line_length) << alignments;
+        break;
+      case oPIR:
+        cout << Formats::PIROut(app_params.line_length) << alignments;
         break;
       default:
         cerr << "Cannot use this format!\n";

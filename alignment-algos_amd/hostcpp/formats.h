@@ -1,4 +1,5 @@
-// formats.h — stream manipulator tags: `in >> Formats::FastaIn() >> seq`, `out << Formats::FastaOut(60) << set`
+// formats.h — stream manipulator tags: `in >> Formats::FastaIn() >> seq`, `out << Formats::FastaOut(60) << set`,
+// `out << Formats::PIROut(60) << set`
 // (reference formats.h:12-48).
 #ifndef ALN_HOST_FORMATS_H
 #define ALN_HOST_FORMATS_H
@@ -8,6 +9,7 @@
 
 struct Formats {
   struct FastaOut { FastaOut(int len = 60) : line_length(len) {} int line_length; };
+  struct PIROut { PIROut(int len = 60) : line_length(len) {} int line_length; };
   struct FastaIn {
     FastaIn(const char* cs = "", bool flag = true) : head_tail(flag), find_me(cs) {}
     bool head_tail;

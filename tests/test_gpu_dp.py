@@ -331,3 +331,37 @@ def test_blocked_exact_kernel_long_rows(direction, blosum62):
             assert np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (p, mode, direction)
             assert np.array_equal(PQ, PQ0) and np.array_equal(PT, PT0), (p, mode, direction)
         b.close()
+
+
+def test_full_size_three_kernels_agree(blosum62):
+    """BASELINE config-2/3 sizes (2000 x 2000): the tagged O(n^2) kernel, the int O(n^2) kernel and the exact-order O(n^3)
+    kernel are three independent programmes for the same recurrence; on integer gaps their score and pointer planes must
+    be identical cell for cell (the O(n^3) oracle is too slow here; it pins each of them at smaller sizes)."""
+    import os
+    alpha, table = blosum62
+    pr = [homolog_pair(1001, 2000), random_pair(1002, 2000), homolog_pair(1003, 1990)]
+    qs, ts = [p[0] for p in pr], [p[1] for p in pr]
+    for mode in (aln_amd.LOCAL, aln_amd.GLOBAL):
+        planes = {}
+        for name, algo, env in (("tag", aln_amd.DP_FAST, None), ("int", aln_amd.DP_FAST, "ALN_NO_TAG_KERNEL"), ("exact", aln_amd.DP_EXACT, None)):
+            if env:
+                os.environ[env] = "1"
+            try:
+                b = aln_amd.Batch(gpu_util.ctx(), qs, ts)
+                b.dp_submatrix(alpha, table, mode, 11, 1, aln_amd.FWD, algo)
+                kn = b.kernel_name()
+                assert {"tag": "dp_affine_tag", "int": "dp_affine_int", "exact": "dp_exact_blocked"}[name] in kn, kn
+                planes[name] = [b.get_cells(p) for p in range(len(pr))]
+                sc, lists, status = b.optimal()
+                planes[name + "_opt"] = (sc, lists)
+                b.close()
+            finally:
+                if env:
+                    del os.environ[env]
+        for other in ("int", "exact"):
+            for p in range(len(pr)):
+                for a, c in zip(planes["tag"][p], planes[other][p]):
+                    assert np.array_equal(np.asarray(a).view(np.uint32), np.asarray(c).view(np.uint32)), (mode, other, p)
+            assert np.array_equal(planes["tag_opt"][0].view(np.uint32), planes[other + "_opt"][0].view(np.uint32))
+            for p in range(len(pr)):
+                assert np.array_equal(planes["tag_opt"][1][p], planes[other + "_opt"][1][p])

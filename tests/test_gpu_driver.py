@@ -37,6 +37,17 @@ def test_aaa_opt_stdout_matches_reference_driver(mode, gi, ge, tmp_path):
     assert out == want
 
 
+@pytest.mark.parametrize("tag,mode,extra", [("m3_pir", 3, ["--OUTPUT_FORMAT", "1"]),
+                                            ("m1_pir40", 1, ["--OUTPUT_FORMAT", "1", "--OUTPUT_LINE_LENGTH", "40"])])
+def test_aaa_pir_stdout_matches_reference_driver(tag, mode, extra, tmp_path):
+    """PIR writer (pirio.h:17-71): per-alignment masks, fix_ends, wrapping — against the real driver's stdout."""
+    out, err = run_driver(["-opt", "--SUB_MATRIX", os.path.join(GOLD, "BLOSUM62"), "--ALIGN_MODE", str(mode), "--GAP_INIT_PENALTY", "11",
+                           "--GAP_EXTN_PENALTY", "1"] + extra + [os.path.join(GOLD, "c1_pair.fa")], tmp_path)
+    with gzip.open(os.path.join(GOLD, "c1_aaa_%s.stdout.gz" % tag), "rt") as f:
+        want = f.read()
+    assert out == want
+
+
 def wrap(s, n=60):
     return [s[i:i + n] for i in range(0, len(s), n)]
 
