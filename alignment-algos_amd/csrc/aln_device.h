@@ -16,8 +16,11 @@ struct EvalDev {
   int Q, T;
   int model, align_type;
   float gi, ge;
-  const float* tgi;     // template-position gap arrays of THIS pair's template (AFFINE_TPOS_MIN) or nullptr
+  const float* tgi;     // template-position gap arrays of THIS pair's template (AFFINE_TPOS_MIN / DEL_TABLE_INS_TPOS) or nullptr
   const float* tge;
+  const float* tcn;     // DEL_TABLE_INS_TPOS: Gn2Eval's v_cn; in the kernel-argument prototype these three are POOL bases
+  const float* deltab;  // DEL_TABLE_INS_TPOS: this template's T x T deletion table (prototype: base of all tables)
+  const int64_t* deltab_off;   // prototype only: first element of template sequence s's table
   // similarity
   int sim_kind;                 // ALN_SIM_SUBMATRIX: codes + table; else plane
   const uint8_t* qc; const uint8_t* tc;
@@ -33,6 +36,8 @@ __device__ __forceinline__ float dev_deletion(const EvalDev& e, int t1, int t2) 
     if (len < 1) return 0.f;
     if (free_end && (t1 == 0 || t2 == e.T - 1)) return 0.f;
     return e.gi + e.ge * (float)(len - 1);
+  } else if (e.model == ALN_GAP_DEL_TABLE_INS_TPOS) {
+    return e.deltab[(size_t)t1 * e.T + t2];     // gn2_eval.h:100-130, materialised by the caller
   } else {
     int dist = t2 - t1;
     if (dist < 2) return 0.f;
@@ -50,6 +55,13 @@ __device__ __forceinline__ float dev_insertion(const EvalDev& e, int q1, int q2,
     if (len < 1) return 0.f;
     if (free_end && (q1 == 0 || q2 == e.Q - 1)) return 0.f;
     return e.gi + e.ge * (float)(len - 1);
+  } else if (e.model == ALN_GAP_DEL_TABLE_INS_TPOS) {   // gn2_eval.h:132-165: coefficients of t1 only, plus the contact-number term
+    int dist = q2 - q1;
+    if (dist < 2) return 0.f;
+    float gp = e.tgi[t1] + e.tge[t1] * (float)(dist - 2);
+    gp = gp + e.tcn[t1];
+    if (free_end && (q1 == 0 || q2 == e.Q - 1)) return 0.f;
+    return gp;
   } else {
     int dist = q2 - q1;
     if (dist < 2) return 0.f;
@@ -58,6 +70,11 @@ __device__ __forceinline__ float dev_insertion(const EvalDev& e, int q1, int q2,
     if (free_end && (q1 == 0 || q2 == e.Q - 1)) return 0.f;
     return gi + ge * (float)(dist - 2);
   }
+}
+// per-pair view of the table-model arrays (the prototype carries pool bases)
+__device__ __forceinline__ void bind_table_model(EvalDev& e, const EvalDev& proto, const PairDesc& pd) {
+  e.tcn = proto.tcn ? proto.tcn + pd.t_off : nullptr;
+  e.deltab = proto.deltab ? proto.deltab + proto.deltab_off[pd.t_seq] : nullptr;
 }
 // DPMatrix::getSim — SimilarityMatrix (simmatrix.h:51-72): zero borders, Evaluator::similarity inside
 __device__ __forceinline__ float dev_sim(const EvalDev& e, int i, int j) {

@@ -73,6 +73,8 @@ struct aln_batch {
   int32_t* d_table32;                          // 32x32 int substitution table (fast path)
   float* d_tablef;                             // 32x32 float table (exact path / getSim)
   float* d_tgi; float* d_tge;                  // AFFINE_TPOS_MIN arrays (template pool positions)
+  float* d_tcn = nullptr; float* d_deltab = nullptr; int64_t* d_deltab_off = nullptr;   // DEL_TABLE_INS_TPOS (Gn2Eval)
+  int32_t n_tseqs = 0;
   int32_t* d_path;                             // traceback output, n_pairs x path_stride x 2
   int32_t path_stride;
   int32_t* d_bounds;

@@ -25,6 +25,7 @@ __global__ __launch_bounds__(64) void dp_corner_kernel(const PairDesc* __restric
   e.tc = tcodes ? tcodes + pd.t_off : nullptr;
   e.tgi = tgi ? tgi + pd.t_off : nullptr;
   e.tge = tge ? tge + pd.t_off : nullptr;
+  bind_table_model(e, proto, pd);
   e.S = Sbase ? Sbase + pd.plane_off : nullptr;
   auto HV = [&](int i, int j) -> float { return load_score(Hbase, pd.plane_off, pd.ld, i, j, h_mode); };
   const int ld = pd.ld, lane = threadIdx.x;
@@ -120,8 +121,9 @@ int launch_dp_corner(aln_batch* b) {
   proto.gi = b->gapdev.gi; proto.ge = b->gapdev.ge;
   proto.sim_kind = (b->sim_kind == ALN_SIM_SUBMATRIX) ? ALN_SIM_SUBMATRIX : ALN_SIM_MATRIX;
   proto.tablef = b->d_tablef;
+  proto.tcn = b->d_tcn; proto.deltab = b->d_deltab; proto.deltab_off = b->d_deltab_off;
   const bool sub = b->sim_kind == ALN_SIM_SUBMATRIX;
-  const bool tpos = b->gapdev.model == ALN_GAP_AFFINE_TPOS_MIN;
+  const bool tpos = b->gapdev.model != ALN_GAP_AFFINE_CONST;
   hipLaunchKernelGGL(dp_corner_kernel, dim3(b->n_pairs), dim3(64), 0, b->ctx->stream, b->d_pairs, proto,
                      sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr,
                      tpos ? b->d_tge : nullptr, b->d_H, b->d_P, sub ? nullptr : b->d_S, b->d_res,

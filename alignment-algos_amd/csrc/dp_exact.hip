@@ -37,6 +37,7 @@ __global__ __launch_bounds__(kExactThreads) void dp_exact_kernel(const PairDesc*
   e.tc = tcodes ? tcodes + pd.t_off : nullptr;
   e.tgi = tgi ? tgi + pd.t_off : nullptr;
   e.tge = tge ? tge + pd.t_off : nullptr;
+  bind_table_model(e, proto, pd);
   e.S = Sbase ? Sbase + pd.plane_off : nullptr;
   float* __restrict__ H = Hbase + pd.plane_off;
   uint32_t* __restrict__ P = Pbase + pd.plane_off;
@@ -134,8 +135,9 @@ int launch_dp_exact(aln_batch* b) {
   proto.gi = b->gapdev.gi; proto.ge = b->gapdev.ge;
   proto.sim_kind = (b->sim_kind == ALN_SIM_SUBMATRIX) ? ALN_SIM_SUBMATRIX : ALN_SIM_MATRIX;
   proto.tablef = b->d_tablef;
+  proto.tcn = b->d_tcn; proto.deltab = b->d_deltab; proto.deltab_off = b->d_deltab_off;
   const bool sub = b->sim_kind == ALN_SIM_SUBMATRIX;
-  const bool tpos = b->gapdev.model == ALN_GAP_AFFINE_TPOS_MIN;
+  const bool tpos = b->gapdev.model != ALN_GAP_AFFINE_CONST;
   const size_t lds = (size_t)2 * (b->maxT + 1) * sizeof(float);
   hipLaunchKernelGGL(dp_exact_kernel, dim3(b->n_pairs), dim3(kExactThreads), lds, ctx->stream, b->d_pairs, proto,
                      sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr,

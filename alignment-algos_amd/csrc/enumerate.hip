@@ -66,6 +66,7 @@ __global__ __launch_bounds__(64) void enumerate_kernel(const PairDesc* __restric
   e.tc = tcodes ? tcodes + pd.t_off : nullptr;
   e.tgi = tgi ? tgi + pd.t_off : nullptr;
   e.tge = tge ? tge + pd.t_off : nullptr;
+  bind_table_model(e, proto, pd);
   e.S = Sbase ? Sbase + pd.plane_off : nullptr;
   auto HV = [&](int i, int j) -> float { return load_score(Hbase, pd.plane_off, pd.ld, i, j, a.h_mode); };
   const int ld = pd.ld, lane = threadIdx.x;
@@ -343,8 +344,9 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   proto.gi = b->gapdev.gi; proto.ge = b->gapdev.ge;
   proto.sim_kind = (b->sim_kind == ALN_SIM_SUBMATRIX) ? ALN_SIM_SUBMATRIX : ALN_SIM_MATRIX;
   proto.tablef = b->d_tablef;
+  proto.tcn = b->d_tcn; proto.deltab = b->d_deltab; proto.deltab_off = b->d_deltab_off;
   const bool sub = b->sim_kind == ALN_SIM_SUBMATRIX;
-  const bool tpos = b->gapdev.model == ALN_GAP_AFFINE_TPOS_MIN;
+  const bool tpos = b->gapdev.model != ALN_GAP_AFFINE_CONST;
   hipLaunchKernelGGL(enumerate_kernel, dim3(1), dim3(64), 0, ctx->stream, b->d_pairs, pair, proto, sub ? b->d_qcodes : nullptr,
                      sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr, b->d_H, b->d_P,
                      sub ? nullptr : b->d_S, a);
@@ -511,8 +513,9 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   proto.gi = b->gapdev.gi; proto.ge = b->gapdev.ge;
   proto.sim_kind = (b->sim_kind == ALN_SIM_SUBMATRIX) ? ALN_SIM_SUBMATRIX : ALN_SIM_MATRIX;
   proto.tablef = b->d_tablef;
+  proto.tcn = b->d_tcn; proto.deltab = b->d_deltab; proto.deltab_off = b->d_deltab_off;
   const bool sub = b->sim_kind == ALN_SIM_SUBMATRIX;
-  const bool tpos = b->gapdev.model == ALN_GAP_AFFINE_TPOS_MIN;
+  const bool tpos = b->gapdev.model != ALN_GAP_AFFINE_CONST;
   for (auto& ev : evs) BTRY(hipEventCreate(&ev));
   BTRY(hipEventRecord(evs[0], ctx->stream));
   hipLaunchKernelGGL(enumerate_kernel, dim3(n), dim3(64), 0, ctx->stream, b->d_pairs, 0, proto, sub ? b->d_qcodes : nullptr,

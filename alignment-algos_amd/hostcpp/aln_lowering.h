@@ -3,9 +3,9 @@
 // The reference calls the evaluator's similarity/deletion/insertion per DP cell (dpmatrix.h:447-486).  Here
 // DPMatrix::build() runs pre_calculate() once, then asks aln::Lowering<S1,S2,Etype> for
 //   * a similarity source:  residue codes + substitution table | a materialised SimilarityMatrix | HMAP profiles
-//   * a gap model from the closed set of include/aln_hip.h (AFFINE_CONST, AFFINE_TPOS_MIN)
+//   * a gap model from the closed set of include/aln_hip.h (AFFINE_CONST, AFFINE_TPOS_MIN, DEL_TABLE_INS_TPOS)
 // and hands both to aln_batch_dp().  The evaluator families of the reference (AASubstitutionEval, Hmap2Eval /
-// HMAPaliEval) have specialisations below / in hmap2_eval.h.  Any other evaluator works through the generic
+// HMAPaliEval, Gn2Eval) have specialisations below / in hmap_eval.h / gn2_eval.h.  Any other evaluator works through the generic
 // path if it says which gap model its deletion()/insertion() implement:
 //
 //     void aln_describe_gaps(const S1& q, const S2& t, aln::GapDescription& g) const;
@@ -42,7 +42,9 @@ struct Lowered {
   std::vector<float> plane;
   int64_t plane_off0;
   std::vector<float> q_aa, q_sse, q_conf, t_aa, t_sse, t_conf;
-  Lowered() : plane_off0(0) { sim = aln_sim(); gap = aln_gap(); }
+  std::vector<float> t_gap_cn, del_table;     // ALN_GAP_DEL_TABLE_INS_TPOS (Gn2Eval)
+  int64_t del_off0;
+  Lowered() : plane_off0(0), del_off0(0) { sim = aln_sim(); gap = aln_gap(); }
   void finish_gap() {
     gap.model = gd.model; gap.align_type = gd.align_type; gap.gap_init = gd.gap_init; gap.gap_extn = gd.gap_extn;
     gap.t_gap_init = gd.t_gap_init.empty() ? 0 : gd.t_gap_init.data();

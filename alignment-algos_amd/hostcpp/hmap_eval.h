@@ -34,7 +34,7 @@ class HMAPaliParams : public AliParams, public NOaliParams {
   bool normalize_mtx;
   float zero_shift;
 };
-typedef HMAPaliParams Gn2Params;   // Hmap2Eval takes a Gn2Params; only its HMAPaliParams part is used (hmap2_eval.h:25)
+class Gn2Params;   // gn2_eval.h; Hmap2Eval takes one and uses only its HMAPaliParams part (hmap2_eval.h:25)
 
 namespace aln {
 // the shared body of HMAPaliEval and Hmap2Eval
@@ -122,7 +122,7 @@ class HMAPaliEval : public aln::HmapEvalBase<HMAPSequence, HMAPaliEval> {
 };
 class Hmap2Eval : public aln::HmapEvalBase<SMAPSequence, Hmap2Eval> {
  public:
-  explicit Hmap2Eval(Gn2Params& p) : aln::HmapEvalBase<SMAPSequence, Hmap2Eval>(p) {}
+  explicit Hmap2Eval(HMAPaliParams& p) : aln::HmapEvalBase<SMAPSequence, Hmap2Eval>(p) {}   // a Gn2Params binds here (derived class)
 };
 
 namespace aln {

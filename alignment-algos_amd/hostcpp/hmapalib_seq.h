@@ -11,6 +11,7 @@
 #include <istream>
 #include <string>
 #include <valarray>
+#include <vector>
 #include "sequence.h"
 #include "sflags.h"
 
@@ -23,6 +24,7 @@ class HMAPElem : public SequenceElem {
   float sse_confid, surfacc_value, surfacc_confid;
   unsigned int lods_type;
   float hydropathy;
+  struct HM_Data { int isse; HM_Data() : isse(-1) {} } rdata;   // index of the SSE the residue belongs to (struct.h; -1 = none)
   HMAPElem() : aa_profile(20), gap_values(4), motif_value(0), motif_confid(0), sse_values(3), sse_confid(0), surfacc_value(0),
                surfacc_confid(0), lods_type(0), hydropathy(0) {}
   explicit HMAPElem(std::istream& in) : aa_profile(20), gap_values(4), sse_values(3) { readHMAP(in); }
@@ -105,11 +107,15 @@ class HMAPSequence : public Sequence<HMAPElem*> {
   HMAPSequence& operator=(const HMAPSequence&);
 };
 
-// Structure-annotated template (reference gn2lib_seq.h): the Troll-derived members are not available on this engine;
-// for Hmap2Eval only the HMAP part is used.
+// Structure-annotated template (reference gn2lib_seq.h:32-57).  The reference fills the structural members from a PDB file
+// through the Troll library, which does not exist here: the caller fills them (plain containers, same names and index
+// conventions).  Hmap2Eval uses only the HMAP part; Gn2Eval (gn2_eval.h) reads all of them.
 class SMAPSequence : public HMAPSequence {
  public:
   explicit SMAPSequence(const char* fn) : HMAPSequence(fn) {}
   explicit SMAPSequence(std::istream& in) : HMAPSequence(in) {}
+  std::vector<std::vector<unsigned long> > brokenhb;     // [i-2][j], i = 2 .. seq_length+1, j < i-1   (gn2_eval.cpp:136-157)
+  std::vector<std::vector<float> > distance;             // same triangular indexing
+  std::vector<float> weighted_contact_number;            // one per element, sentinels included (seq_length + 2)
 };
 #endif

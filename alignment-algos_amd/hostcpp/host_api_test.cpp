@@ -1,13 +1,17 @@
 // host_api_test.cpp — exercises the C++ host mirror end to end on the GPU (used by tests/test_gpu_hostcpp.py):
 //   profile <mode> <q.hmap> <t.hmap>      DPMatrix<HMAPSequence,SMAPSequence,Hmap2Eval> + Optimal -> score bits, pairs, probes
 //   aa <mode> <gi> <ge> <dir> <q> <t> <blosum>   DPMatrix<AASequence,...> fwd/rev + Optimal/Optimal_Rev + ucw, cells via getCell
+//   gn2 <mode> <q.hmap> <t.hmap> <seed>   DPMatrix<HMAPSequence,SMAPSequence,Gn2Eval> with synthetic structural members; prints the
+//                                         tables pre_calculate built (TAB name n v...) so a test can feed them to its checker
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include "aa_seq.h"
 #include "aasubalib.h"
 #include "cw.h"
 #include "dpmatrix.h"
+#include "gn2_eval.h"
 #include "hmap2_eval.h"
 #include "optimal.h"
 #include "optimal_rev.h"
@@ -44,6 +48,48 @@ int main(int argc, char** argv) {
       printf("\nS");
       for (int i = 0; i < Q; ++i) for (int j = 0; j < T; ++j) printf(" %08x", fbits(dpm.getSim(i, j)));
       printf("\n");
+      return 0;
+    }
+    if (cmd == "gn2") {
+      Gn2Params p;
+      p.align_type = (align_t)atoi(argv[2]);
+      HMAPSequence q(argv[3]);
+      SMAPSequence t(argv[4]);
+      unsigned long long st = strtoull(argv[5], 0, 10) * 2862933555777941757ull + 3037000493ull;
+      auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (float)((st >> 40) & 0xFFFFFF) / 16777216.0f; };
+      const int T = (int)t.size(), n = (int)t.seq_length;
+      // structural members the reference derives from a PDB file through Troll: synthetic here
+      t.weighted_contact_number.resize(T);
+      for (int i = 0; i < T; ++i) { t.weighted_contact_number[i] = 0.2f + rnd(); t[i]->hydropathy = rnd(); t[i]->rdata.isse = (int)(rnd() * 6) - 1; }
+      for (size_t i = 0; i < q.size(); ++i) q[i]->hydropathy = rnd();
+      t.distance.resize(n); t.brokenhb.resize(n);
+      for (int i = 2; i < n + 2; ++i) {
+        t.distance[i - 2].resize(i - 1); t.brokenhb[i - 2].resize(i - 1);
+        for (int j = 0; j < i - 1; ++j) { t.distance[i - 2][j] = 3.f + 25.f * rnd(); t.brokenhb[i - 2][j] = (unsigned long)(rnd() * 4); }
+      }
+      Gn2Eval ev(p);
+      DPMatrix<HMAPSequence, SMAPSequence, Gn2Eval> dpm(q, t, ev, fwd, p.align_type);
+      Optimal<HMAPSequence, SMAPSequence, Gn2Eval> opt(p.align_type);
+      AlignmentSet<HMAPSequence, SMAPSequence, Gn2Eval> as(dpm, opt);
+      dump("OPT", as);
+      const int Q = dpm.getQuerySize();
+      printf("DIM %d %d\nH", Q, T);
+      for (int i = 0; i < Q; ++i) for (int j = 0; j < T; ++j) printf(" %08x", fbits(dpm.getCell(i, j)->score));
+      printf("\nPQ");
+      for (int i = 0; i < Q; ++i) for (int j = 0; j < T; ++j) printf(" %d", dpm.getCell(i, j)->prev_query_idx);
+      printf("\nPT");
+      for (int i = 0; i < Q; ++i) for (int j = 0; j < T; ++j) printf(" %d", dpm.getCell(i, j)->prev_template_idx);
+      printf("\nS");
+      for (int i = 0; i < Q; ++i) for (int j = 0; j < T; ++j) printf(" %08x", fbits(dpm.getSim(i, j)));
+      printf("\n");
+      auto vec = [&](const char* name, const std::vector<float>& v) { printf("TAB %s", name); for (int j = 0; j < T; ++j) printf(" %08x", fbits(j < (int)v.size() ? v[j] : 0.f)); printf("\n"); };
+      vec("v_gi", ev.v_gi); vec("v_ge", ev.v_ge); vec("v_cn", ev.v_cn);
+      auto tri = [&](const char* name, const std::vector<std::vector<float> >& v) {   // T x T, [p2*T + p1], zero where undefined
+        printf("TAB %s", name);
+        for (int p2 = 0; p2 < T; ++p2) for (int p1 = 0; p1 < T; ++p1) printf(" %08x", fbits(p2 < (int)v.size() && p1 < (int)v[p2].size() ? v[p2][p1] : 0.f));
+        printf("\n");
+      };
+      tri("dist", t.distance); tri("vv_gi", ev.vv_gi); tri("vv_ge", ev.vv_ge); tri("vv_cd", ev.vv_cd);
       return 0;
     }
     AliParams p;

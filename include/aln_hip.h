@@ -34,7 +34,9 @@ enum aln_direction_t { ALN_FWD = 1, ALN_REV = 2 };   /* dpmatrix.h:23-26 */
 
 enum aln_gap_model {
   ALN_GAP_AFFINE_CONST = 0,     /* AASubstitutionEval::deletion/insertion, aasubalib.h:27-77 */
-  ALN_GAP_AFFINE_TPOS_MIN = 1   /* Hmap2Eval / HMAPaliEval, hmap2_eval.h:41-95 (min of the two template positions) */
+  ALN_GAP_AFFINE_TPOS_MIN = 1,  /* Hmap2Eval / HMAPaliEval, hmap2_eval.h:41-95 (min of the two template positions) */
+  ALN_GAP_DEL_TABLE_INS_TPOS = 2 /* Gn2Eval, gn2_eval.h:100-165: deletion(t1,t2) is a per-template table (vv_gi/vv_ge/vv_cd + the
+                                   8100 distance rule, materialised by the caller), insertion = (gi[t1] + ge[t1]*(di-2)) + cn[t1] */
 };
 
 enum aln_sim_kind {
@@ -106,6 +108,12 @@ typedef struct {
   const float* t_gap_extn;
   int32_t dp_local;             /* the DPMatrix constructor's own `type == local` (dpmatrix.h:155) when it differs from the
                                    evaluator's align_type: 0 = same as align_type, 1 = not local, 2 = local */
+  /* DEL_TABLE_INS_TPOS only.  t_gap_init / t_gap_extn / t_gap_cn are Gn2Eval's v_gi / v_ge / v_cn per residue of the TEMPLATE
+   * pool (gn2_eval.cpp:113-130).  del_table: template sequence s (T residues) owns T*T floats at del_table[del_table_off[s]],
+   * entry [t1*T + t2] = exactly what Evaluator::deletion(q,t,.,.,t1,t2) returns for t1 < t2 (end rules included). */
+  const float* t_gap_cn;
+  const float* del_table;
+  const int64_t* del_table_off; /* n template sequences */
 } aln_gap;
 
 /* Similarity source. */

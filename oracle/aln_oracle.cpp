@@ -36,6 +36,22 @@ extern "C" {
 // aasubalib.h:27-51 / hmap2_eval.h:41-67
 float orc_deletion(const orc_gap* g, int Q, int T, int q1, int q2, int t1, int t2, int* err) {
   (void)Q; (void)q1; (void)q2;
+  if (g->model == ORC_GAP_GN2) {                   // gn2_eval.h:100-130
+    int di = t2 - t1;
+    if (di < 2) return 0;
+    int p1 = t1, p2 = t2 - 2;
+    float GP = 8100.f;
+    if (g->dist[(size_t)p2 * T + p1] < 18.f)
+      GP = g->vvgi[(size_t)p2 * T + p1] + g->vvge[(size_t)p2 * T + p1] * (di - 2) + g->vvcd[(size_t)p2 * T + p1];
+    switch (g->align_type) {
+      case ORC_GLOBAL: case ORC_GLOBAL_LOCAL:
+        return GP;
+      case ORC_LOCAL: case ORC_SEMI_LOCAL: case ORC_LOCAL_GLOBAL:
+        if (t1 == 0 || t2 == T - 1) return 0;
+        return GP;
+      default: if (err) *err = ORC_E_GAPSTYLE; return 0.f;
+    }
+  }
   if (g->model == ORC_GAP_AFFINE_CONST) {
     int len = t2 - t1 - 1;
     if (len < 1) return 0.f;
@@ -66,6 +82,19 @@ float orc_deletion(const orc_gap* g, int Q, int T, int q1, int q2, int t1, int t
 // aasubalib.h:53-77 / hmap2_eval.h:69-95 (coefficients come from the TEMPLATE positions t1,t2)
 float orc_insertion(const orc_gap* g, int Q, int T, int q1, int q2, int t1, int t2, int* err) {
   (void)T;
+  if (g->model == ORC_GAP_GN2) {                   // gn2_eval.h:132-165
+    int di = q2 - q1;
+    if (di < 2) return 0;
+    float GP = g->tgi[t1] + g->tge[t1] * (di - 2) + g->tcn[t1];
+    switch (g->align_type) {
+      case ORC_GLOBAL: case ORC_LOCAL_GLOBAL:
+        return GP;
+      case ORC_LOCAL: case ORC_SEMI_LOCAL: case ORC_GLOBAL_LOCAL:
+        if (q1 == 0 || q2 == Q - 1) return 0;
+        return GP;
+      default: if (err) *err = ORC_E_GAPSTYLE; return 0.f;
+    }
+  }
   if (g->model == ORC_GAP_AFFINE_CONST) {
     int len = q2 - q1 - 1;
     if (len < 1) return 0.f;

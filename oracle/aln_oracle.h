@@ -32,14 +32,21 @@ enum { ORC_GLOBAL_LOCAL = 0, ORC_GLOBAL = 1, ORC_LOCAL_GLOBAL = 2, ORC_LOCAL = 3
 enum { ORC_FWD = 1, ORC_REV = 2 };
 /* gap models */
 enum { ORC_GAP_AFFINE_CONST = 0,    /* AASubstitutionEval, aasubalib.h:27-77 */
-       ORC_GAP_AFFINE_TPOS_MIN = 1  /* Hmap2Eval / HMAPaliEval, hmap2_eval.h:41-95 */ };
+       ORC_GAP_AFFINE_TPOS_MIN = 1, /* Hmap2Eval / HMAPaliEval, hmap2_eval.h:41-95 */
+       ORC_GAP_GN2 = 2              /* Gn2Eval, gn2_eval.h:100-165 — parity UNPINNED (its inputs come from the absent Troll library) */ };
 
 typedef struct {
   int model;
   int align_type;
   float gi, ge;            /* model 0 */
-  const float* tgi;        /* model 1: per template position, length T */
+  const float* tgi;        /* model 1: per template position, length T; model 2: Gn2Eval's v_gi / v_ge */
   const float* tge;
+  /* model 2 (gn2_eval.cpp:113-158): v_cn per template position; distance, vv_gi, vv_ge, vv_cd as T x T arrays [p2*T + p1] */
+  const float* tcn;
+  const float* dist;
+  const float* vvgi;
+  const float* vvge;
+  const float* vvcd;
 } orc_gap;
 
 /* error codes mirror the reference's throw sites */

@@ -13,12 +13,14 @@ _LIB = None
 
 GLOBAL_LOCAL, GLOBAL, LOCAL_GLOBAL, LOCAL, SEMI_LOCAL = 0, 1, 2, 3, 4
 FWD, REV = 1, 2
-GAP_AFFINE_CONST, GAP_AFFINE_TPOS_MIN = 0, 1
+GAP_AFFINE_CONST, GAP_AFFINE_TPOS_MIN, GAP_GN2 = 0, 1, 2
 
 
 class OrcGap(C.Structure):
     _fields_ = [("model", C.c_int), ("align_type", C.c_int), ("gi", C.c_float), ("ge", C.c_float),
-                ("tgi", C.POINTER(C.c_float)), ("tge", C.POINTER(C.c_float))]
+                ("tgi", C.POINTER(C.c_float)), ("tge", C.POINTER(C.c_float)), ("tcn", C.POINTER(C.c_float)),
+                ("dist", C.POINTER(C.c_float)), ("vvgi", C.POINTER(C.c_float)), ("vvge", C.POINTER(C.c_float)),
+                ("vvcd", C.POINTER(C.c_float))]
 
 
 def build():
@@ -60,10 +62,17 @@ def f32(x):
 class Gap:
     """Gap model descriptor; keeps numpy arrays alive."""
 
-    def __init__(self, align_type, gi=0.0, ge=0.0, tgi=None, tge=None):
+    def __init__(self, align_type, gi=0.0, ge=0.0, tgi=None, tge=None, gn2=None):
         self.g = OrcGap()
         self.g.align_type = int(align_type)
-        if tgi is None:
+        if gn2 is not None:
+            # Gn2Eval tables: dict v_gi, v_ge, v_cn [T]; dist, vv_gi, vv_ge, vv_cd [T,T] indexed [p2, p1]
+            self.g.model = GAP_GN2
+            self.keep = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in gn2.items()}
+            self.g.tgi, self.g.tge, self.g.tcn = _fp(self.keep["v_gi"]), _fp(self.keep["v_ge"]), _fp(self.keep["v_cn"])
+            self.g.dist, self.g.vvgi = _fp(self.keep["dist"]), _fp(self.keep["vv_gi"])
+            self.g.vvge, self.g.vvcd = _fp(self.keep["vv_ge"]), _fp(self.keep["vv_cd"])
+        elif tgi is None:
             self.g.model = GAP_AFFINE_CONST
             self.g.gi = float(np.float32(gi))
             self.g.ge = float(np.float32(ge))

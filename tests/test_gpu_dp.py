@@ -365,3 +365,71 @@ def test_full_size_three_kernels_agree(blosum62):
             assert np.array_equal(planes["tag_opt"][0].view(np.uint32), planes[other + "_opt"][0].view(np.uint32))
             for p in range(len(pr)):
                 assert np.array_equal(planes["tag_opt"][1][p], planes[other + "_opt"][1][p])
+
+
+def gn2_tables(rng, T):
+    """Synthetic Gn2Eval::pre_calculate outputs (gn2_eval.cpp:113-158) for a template of T positions: v_gi/v_ge/v_cn and the
+    (p2,p1)-indexed distance / vv_gi / vv_ge / vv_cd tables.  Real inputs come from the Troll library (absent)."""
+    t = {"v_gi": rng.uniform(3, 9, T), "v_ge": rng.uniform(0.1, 0.9, T), "v_cn": rng.uniform(-0.5, 1.5, T),
+         "dist": rng.uniform(3, 30, (T, T)), "vv_gi": rng.choice([4.0, 9.5], (T, T)), "vv_ge": rng.choice([0.2, 0.7], (T, T)),
+         "vv_cd": np.exp(rng.uniform(-6, 1, (T, T)))}
+    return {k: v.astype(np.float32) for k, v in t.items()}
+
+
+def gn2_deletion_table(tb, T, mode):
+    """What a host lowering of Gn2Eval materialises: deletion(t1,t2) for every t1 < t2 (gn2_eval.h:100-130), fp32."""
+    D = np.zeros((T, T), dtype=np.float32)
+    for t1 in range(T):
+        for t2 in range(t1 + 2, T):
+            p1, p2 = t1, t2 - 2
+            gp = np.float32(8100.0)
+            if tb["dist"][p2, p1] < np.float32(18.0):
+                gp = np.float32(np.float32(tb["vv_gi"][p2, p1] + np.float32(tb["vv_ge"][p2, p1] * np.float32(t2 - t1 - 2))) + tb["vv_cd"][p2, p1])
+            if mode in (3, 4, 2) and (t1 == 0 or t2 == T - 1):
+                gp = np.float32(0.0)
+            D[t1, t2] = gp
+    return D
+
+
+@pytest.mark.parametrize("direction", ["fwd", "rev"])
+def test_gn2_table_gap_model(direction):
+    """ALN_GAP_DEL_TABLE_INS_TPOS (Gn2Eval's gap functions): table deletions, (gi[t1] + ge[t1] (di-2)) + cn[t1] insertions, all
+    five end-gap styles, DP + Optimal + constrained enumeration vs the oracle's restatement.  Parity UNPINNED against the
+    reference itself (Gn2Eval cannot be built without Troll); this pins kernel == oracle."""
+    rng = np.random.RandomState(5)
+    dims = [(9, 14), (40, 33), (66, 90)]
+    planes, tabs = [], []
+    for (Q, T) in dims:
+        S = rng.normal(0.1, 1.2, size=(Q, T)).astype(np.float32)
+        S[0, :] = 0; S[-1, :] = 0; S[:, 0] = 0; S[:, -1] = 0
+        planes.append(S)
+        tabs.append(gn2_tables(rng, T))
+    pool = {k: np.concatenate([tb[k] for tb in tabs]) for k in ("v_gi", "v_ge", "v_cn")}
+    for mode in range(5):
+        b = aln_amd.Batch(gpu_util.ctx(), ["A" * (Q - 2) for Q, T in dims], ["A" * (T - 2) for Q, T in dims])
+        dels = [gn2_deletion_table(tb, T, mode) for tb, (Q, T) in zip(tabs, dims)]
+        b.dp_simmatrix(planes, mode, 0, 0, DIRS[direction], tgi=pool["v_gi"], tge=pool["v_ge"], tcn=pool["v_cn"], del_tables=dels)
+        assert "dp_exact_kernel" in b.kernel_name()
+        scores, lists, status = b.optimal()
+        for p, S in enumerate(planes):
+            gap = orc.Gap(mode, gn2=tabs[p])
+            rc, D0, PQ0, PT0 = orc.dp_build(S, gap, orc.FWD if direction == "fwd" else orc.REV)
+            D, PQ, PT = b.get_cells(p)
+            assert np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (p, mode, direction)
+            assert np.array_equal(PQ, PQ0) and np.array_equal(PT, PT0), (p, mode, direction)
+            rc2, sc, pairs = orc.optimal(D0, PQ0, PT0, mode == 3, kind=direction)
+            assert np.float32(scores[p]).view(np.uint32) == sc.view(np.uint32)
+            assert np.array_equal(lists[p], pairs)
+            if direction == "fwd" and mode in (1, 4):
+                T = dims[p][1]
+                flags = orc.make_subopt_regions(T, 3)
+                s = orc.AliSet()
+                s.push(pairs, sc)
+                orc.enumerate_noa("cw", D0, PQ0, PT0, S, gap, flags, 12, 0.1, s)
+                got = b.enumerate(p, "cw", 12, 0.1, flags, max_alignments=max(12, len(s)) + 2)
+                assert len(got) == len(s)
+                for k, g in enumerate(got):
+                    r = s.get(k)
+                    assert np.float32(g["score"]).view(np.uint32) == r["score"].view(np.uint32), (p, mode, k)
+                    assert np.array_equal(g["pairs"], r["pairs"])
+        b.close()

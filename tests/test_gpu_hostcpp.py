@@ -63,6 +63,36 @@ def test_hmap2eval_through_host_classes(mode, tmp_path):
     assert a["score"].view(np.uint32) == sc.view(np.uint32) and np.array_equal(a["pairs"], pairs)
 
 
+@pytest.mark.parametrize("mode", [1, 4, 3])
+def test_gn2eval_through_host_classes(mode, tmp_path):
+    """Gn2Eval (hostcpp/gn2_eval.h) lowered to a host similarity plane + ALN_GAP_DEL_TABLE_INS_TPOS: the program prints the
+    tables its pre_calculate built; the oracle's restatement of the gap functions (gn2_eval.h:100-165) on those tables must
+    give the same matrices.  Parity UNPINNED against the reference itself (needs Troll)."""
+    qp, tp = random_profile(94000, 29), random_profile(95000, 41)
+    write_hmap(str(tmp_path / "q.hmap"), "query", qp)
+    write_hmap(str(tmp_path / "t.hmap"), "templ", tp)
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "alignment-algos_amd")])
+    r = subprocess.run([EXE, "gn2", str(mode), str(tmp_path / "q.hmap"), str(tmp_path / "t.hmap"), "7"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "THROW" not in r.stdout, r.stdout[:500] + r.stderr
+    got = refrun.parse(r.stdout)
+    Q, T = got["dim"]
+    tabs = {}
+    for line in r.stdout.split("\n"):
+        if line.startswith("TAB "):
+            tk = line.split()
+            a = np.array([int(x, 16) for x in tk[2:]], dtype=np.uint32).view(np.float32)
+            tabs[tk[1]] = a.reshape(T, T) if len(a) == T * T else a
+    gap = orc.Gap(mode, gn2=tabs)
+    rc, D, PQ, PT = orc.dp_build(got["S"], gap, islocal=(mode == 3))
+    assert np.array_equal(got["H"].view(np.uint32), D.view(np.uint32))
+    assert np.array_equal(got["PQ"], PQ) and np.array_equal(got["PT"], PT)
+    rc2, sc, pairs = orc.optimal(D, PQ, PT, mode == 3)
+    a = got["sets"]["OPT"]["alis"][0]
+    assert a["score"].view(np.uint32) == sc.view(np.uint32) and np.array_equal(a["pairs"], pairs)
+    assert np.isfinite(got["S"]).all() and (got["S"][1:-1, 1:-1] != 0).any()
+
+
 @pytest.mark.parametrize("mode,gi,ge,direction", [(3, 11, 1, "fwd"), (4, 4.73, 0.34, "fwd"), (1, 11, 1, "rev"), (3, 4.73, 0.34, "rev")])
 def test_aa_path_through_host_classes(mode, gi, ge, direction, blosum62):
     alpha, table = blosum62
