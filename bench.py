@@ -48,7 +48,7 @@ def cpu_baseline(qs, ts, mode, gi, ge):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, len(qs), 32))
+    cores = max(1, min(cores, len(qs), 16))      # the GPU box gives one GPU a 16-core share
     cells = sum(len(qs[p]) * len(ts[p]) for p in range(cores))
     sample = "%d pairs %dx%d of the bench workload (rank 0, pairs 0..%d), one pair per core, DPMatrix build only" % (
         cores, len(qs[0]), len(ts[0]), cores - 1)
