@@ -356,6 +356,374 @@ __global__ __launch_bounds__(kBT, 2) void dp_exact_blocked_kernel(const PairDesc
   }
 }
 
+
+// =====================================================================================================================
+// dp_exact_tiled_kernel — same results again, with the deletion scan shared between rows.
+//
+// The gap of a deletion (k -> b) does not depend on the row, only the source value D[a-1][k] does.  Rows go in blocks
+// of 16 and columns in tiles of 256 (one column per thread), tiles left to right inside a row block.  For a tile
+// starting at column b0 every source column k <= b0-2 of the 16 source rows a0-1 .. a0+14 is final (earlier tiles of
+// this block, or the previous block), so the "far-left" part of all 16 deletion scans is one loop: per (k, b) the gap
+// g(k,b) is formed ONCE (min, min, mul, add) and applied to 16 rows (sub, max each) — 2.3 VALU ops per candidate instead
+// of 7.  The 16 source values per k are wave-uniform: they come through the scalar cache (s_load_dwordx2 from a
+// frame-ordered copy of the finished rows) and enter the VALU as SGPR operands, so neither LDS nor VGPRs carry them.
+// The remaining candidates k in [b0-1, b-2] (inside the tile, <= 255) are scanned per row from LDS exactly like
+// dp_exact_blocked does, starting from the far-left (max, e, chunk) state, so the "first k" bookkeeping is unchanged.
+// Far insertions: the 16-row sliding window of dp_exact_blocked, per tile.
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v sload2(const float* p) {
+  f2v v;
+  asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
+typedef float f4v __attribute__((ext_vector_type(4)));
+// s_load_dwordx4 with an immediate byte offset (the 16 source rows of a row block sit PT floats apart in the scratch ring)
+template <int OFF>
+__device__ __forceinline__ f4v sload4_imm(const float* p) {
+  f4v v;
+  asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(v) : "s"(p), "n"(OFF) : "memory");
+  return v;
+}
+template <int R, int NR, int PTC>
+__device__ __forceinline__ void sload_rows(f4v (&dst)[NR], const float* p) {
+  if constexpr (R < NR) {
+    dst[R] = sload4_imm<R * PTC * 4>(p);
+    sload_rows<R + 1, NR, PTC>(dst, p);
+  }
+}
+__device__ __forceinline__ void swait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ float vmin_sv(float s, float v) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "s"(s), "v"(v)); return r; }
+
+constexpr int kTW = 256;       // tile width = threads
+constexpr int kTRing = 32;     // frame-ordered copies of finished rows kept per workgroup (>= kBR + 1)
+constexpr int kTLoc = 320;     // tile-local row buffer: 257 live entries + pads the masked tail may read
+
+template <int PT, bool TPOS, bool LOCAL>
+__global__ __launch_bounds__(kTW, 2) void dp_exact_tiled_kernel(const PairDesc* __restrict__ pairs, EvalDev proto,
+                                                                 const uint8_t* __restrict__ qcodes, const uint8_t* __restrict__ tcodes,
+                                                                 const float* __restrict__ tgi, const float* __restrict__ tge,
+                                                                 float* __restrict__ Hbase, uint32_t* __restrict__ Pbase,
+                                                                 const float* __restrict__ Sbase, PairResult* __restrict__ res, int rev,
+                                                                 float* __restrict__ scratch_base) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float2* tg = reinterpret_cast<float2*>(lds);          // (tgi, tge) in frame order, PT entries
+  float* rowloc0 = lds + 2 * PT;                         // rows a-1 / a of the current tile, index k - kbase
+  float* rowloc1 = rowloc0 + kTLoc;
+  float* fdm = rowloc1 + kTLoc;                          // far-left deletion results [kBR][kTW] (own words only)
+  float* fde = fdm + kBR * kTW;
+  int* fdc = reinterpret_cast<int*>(fde + kBR * kTW);
+  __shared__ float red_v[kTW / 64];
+  __shared__ uint32_t red_p[kTW / 64];
+  const float ninf = -__builtin_inff();
+
+  const PairDesc pd = pairs[blockIdx.x];
+  EvalDev e = proto;
+  e.Q = pd.Q; e.T = pd.T; e.ld = pd.ld;
+  e.qc = qcodes ? qcodes + pd.q_off : nullptr;
+  e.tc = tcodes ? tcodes + pd.t_off : nullptr;
+  e.tgi = tgi ? tgi + pd.t_off : nullptr;
+  e.tge = tge ? tge + pd.t_off : nullptr;
+  e.S = Sbase ? Sbase + pd.plane_off : nullptr;
+  float* __restrict__ H = Hbase + pd.plane_off;
+  uint32_t* __restrict__ P = Pbase + pd.plane_off;
+  const int ld = pd.ld;
+  const Frame f = {pd.q0, pd.q1, pd.t0, pd.t1, rev};
+  const int nQ = f.nQ(), nT = f.nT();
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const float gi_c = e.gi, ge_c = e.ge;
+  // per-workgroup scratch: far-insertion results [3][kBR][PT], finished rows in frame order [kTRing][PT], (tgi, tge) [2][PT]
+  float* scr_m = scratch_base + (size_t)blockIdx.x * (size_t)(3 * kBR + kTRing + 2) * PT;
+  float* scr_e = scr_m + kBR * PT;
+  int* scr_c = reinterpret_cast<int*>(scr_e + kBR * PT);
+  float* rowsF = scr_m + 3 * kBR * PT;
+  float* tgiF = rowsF + kTRing * PT;
+  float* tgeF = tgiF + PT;
+
+  float lmax = 0.f; uint32_t lpos = 0xFFFFFFFFu;
+  const uint32_t origin = pack_ptr(f.rq(0), f.rt(0));
+
+  if (nQ >= 2 && nT >= 2) {
+    for (int x = tid; x < PT; x += kTW) {
+      float2 v = {0.f, 0.f};
+      if (TPOS && x <= nT) { const int pos = f.rt(x); v.x = e.tgi[pos]; v.y = e.tge[pos]; }
+      tg[x] = v;
+      tgiF[x] = v.x; tgeF[x] = v.y;
+    }
+    for (int x = tid; x < 2 * kTLoc; x += kTW) rowloc0[x] = ninf;
+    __threadfence_block();
+    __syncthreads();
+    const int ntiles = (nT - 1 + kTW - 1) / kTW;
+
+    for (int a0 = 1; a0 <= nQ - 1; a0 += kBR) {
+      const int a_end = (a0 + kBR - 1 < nQ - 1) ? a0 + kBR - 1 : nQ - 1;
+      for (int cb = 0; cb < ntiles; ++cb) {
+        const int kbase = kTW * cb;                    // = b0 - 1: first near source column of the tile
+        const int bc = kbase + 1 + tid;                // this thread's column
+        const bool bv = bc <= nT - 1;
+        const bool wave_on = kbase + 1 + 64 * wave <= nT - 1;
+        // ============ far insertions of rows a0 .. a0+15 for column bc: candidates k = 1 .. a0-2 =====================
+        if (a0 >= 3 && wave_on) {
+          const int b = (bc < 2 || !bv) ? 2 : bc;
+          float gi = gi_c, ge = ge_c;
+          if (TPOS) { const float2 t0 = tg[b - 1], t1 = tg[b]; gi = fminr(t0.x, t1.x); ge = fminr(t0.y, t1.y); }
+          const size_t colb = (size_t)f.rt(b - 1);
+          float W[kBR], cm[kBR], m[kBR], ee[kBR]; int cc[kBR];
+          float fn = (float)(a0 - 2);
+#pragma unroll
+          for (int i = 0; i < kBR; ++i) { W[i] = gi + ge * (fn + (float)i); cm[i] = ninf; m[i] = ninf; ee[i] = ninf; cc[i] = 0; }
+          for (int kc = 0; kc <= a0 - 2; kc += kBR) {
+            float x[kBR];
+#pragma unroll
+            for (int u = 0; u < kBR; ++u) {
+              const int k = kc + u;
+              x[u] = (k >= 1 && k <= a0 - 2) ? aload(&H[(size_t)f.rq(k) * ld + colb]) : ninf;
+            }
+#pragma unroll
+            for (int u = 0; u < kBR; ++u) {
+#pragma unroll
+              for (int r = 0; r < kBR; ++r) cm[r] = vmaxf(cm[r], x[u] - W[(r - u) & (kBR - 1)]);
+              fn -= 1.0f;
+              W[kBR - 1 - u] = gi + ge * fn;
+            }
+#pragma unroll
+            for (int r = 0; r < kBR; ++r) {
+              const bool up = cm[r] > m[r];
+              ee[r] = up ? m[r] : ee[r];
+              cc[r] = up ? kc : cc[r];
+              m[r] = up ? cm[r] : m[r];
+              cm[r] = ninf;
+            }
+          }
+          if (bv && bc >= 2) {
+#pragma unroll
+            for (int r = 0; r < kBR; ++r) { scr_m[r * PT + bc] = m[r]; scr_e[r * PT + bc] = ee[r]; scr_c[r * PT + bc] = cc[r]; }
+          }
+        }
+        // ============ far-left deletions: sources k = 1 .. kbase-1 of rows a0-1 .. a0+14, shared gap values ===========
+        if (cb >= 1 && a_end >= 2 && wave_on) {
+          __builtin_amdgcn_s_dcache_inv();             // the source rows were written through the vector path
+          const int b = bv ? bc : kbase + 1;
+          float gib = 0.f, geb = 0.f;
+          if (TPOS) { const float2 t = tg[b]; gib = t.x; geb = t.y; }
+          float fd = (float)(b - 2);
+          float cm[kBR], m[kBR], ee[kBR]; int cc[kBR];
+#pragma unroll
+          for (int r = 0; r < kBR; ++r) { cm[r] = ninf; m[r] = ninf; ee[r] = ninf; cc[r] = 0; }
+          // source row of target row a0+r is a0+r-1: ring slots (a0-1) & 31 + r — consecutive, because a0-1 is a multiple of 16
+          const float* sbase = rowsF + (size_t)((a0 - 1) & (kTRing - 1)) * PT;
+          for (int kc = 0; kc < kbase; kc += kBC) {
+#pragma unroll 1
+            for (int k = kc; k < kc + kBC; k += 4) {
+              f4v src[kBR];
+              sload_rows<0, kBR, PT>(src, sbase + k);
+              f4v gk = {0.f, 0.f, 0.f, 0.f}, ek = {0.f, 0.f, 0.f, 0.f};
+              if (TPOS) { gk = sload4_imm<0>(tgiF + k); ek = sload4_imm<PT * 4>(tgiF + k); }
+              swait_lgkm0();
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const float gi = TPOS ? vmin_sv(gk[u], gib) : gi_c;
+                const float ge = TPOS ? vmin_sv(ek[u], geb) : ge_c;
+                const float g = gi + ge * fd;
+                fd -= 1.0f;
+                if (k + u == 0) continue;              // column 0 is never a source (dpmatrix.h:459 starts at t0+1)
+#pragma unroll
+                for (int r = 0; r < kBR; ++r) cm[r] = vmaxf(cm[r], src[r][u] - g);
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < kBR; ++r) {
+              const bool up = cm[r] > m[r];
+              ee[r] = up ? m[r] : ee[r];
+              cc[r] = up ? kc : cc[r];
+              m[r] = up ? cm[r] : m[r];
+              cm[r] = ninf;
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < kBR; ++r) { fdm[r * kTW + tid] = m[r]; fde[r * kTW + tid] = ee[r]; fdc[r * kTW + tid] = cc[r]; }
+        }
+        // ============ tile prologue: row a0-1 of the tile's columns (and column b0-1) into the local buffer ==========
+        {
+          float* pv = ((a0 - 1) & 1) ? rowloc1 : rowloc0;
+          const float* src = rowsF + (size_t)((a0 - 1) & (kTRing - 1)) * PT;
+          float v = ninf;
+          if (a0 >= 2 && bv) v = aload(&src[bc]);
+          pv[1 + tid] = v;
+          if (tid == 0) pv[0] = (a0 >= 2 && cb >= 1) ? aload(&src[kbase]) : ninf;
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+
+        // ============ the rows of the block inside this tile ==========================================================
+        for (int a = a0; a <= a_end; ++a) {
+          const int i = f.rq(a);
+          const int r = a - a0;
+          float* prevl = ((a - 1) & 1) ? rowloc1 : rowloc0;
+          float* curl = (a & 1) ? rowloc1 : rowloc0;
+          const float* prev = prevl - kbase;            // prev[k] for absolute k in [kbase, kbase + kTLoc)
+          float* rowF = rowsF + (size_t)(a & (kTRing - 1)) * PT;
+          if (wave_on) {
+            const bool valid = bv;
+            const int bb = valid ? bc : 1;
+            const int jj = f.rt(bb);
+            const float sim = dev_sim(e, i, jj);
+            float opt; uint32_t optp;
+            if (a == 1) {                                   // first row: dpmatrix.h:409-418
+              float sv = 0.f;
+              if (bb > 1) sv -= frame_del(e, f, 0, bb);
+              sv += sim;
+              opt = clip0(sv, LOCAL); optp = origin;
+            } else if (bb == 1) {                           // first column: :421-426
+              float sv = 0.f;
+              sv -= frame_ins(e, f, 0, a, 0, 1);
+              sv += sim;
+              opt = clip0(sv, LOCAL); optp = origin;
+            } else {
+              // ---- deletion scan: far-left state, then the tile's own columns from LDS ------------------------------
+              ScanState<1> s;
+              if (TPOS) { const float2 t = tg[bb]; s.gib[0] = t.x; s.geb[0] = t.y; } else { s.gib[0] = 0.f; s.geb[0] = 0.f; }
+              s.fd[0] = (float)(bb - kbase - 2);
+              s.cm[0] = ninf;
+              if (cb >= 1) { s.m[0] = fdm[r * kTW + tid]; s.e[0] = fde[r * kTW + tid]; s.cidx[0] = fdc[r * kTW + tid]; }
+              else { s.m[0] = ninf; s.e[0] = ninf; s.cidx[0] = 0; }
+              const int tail = kbase + 64 * wave;
+              scan_range<0, 1, TPOS, false>(s, prev, tg, kbase, tail, gi_c, ge_c);
+              scan_range<0, 1, TPOS, true>(s, prev, tg, tail, tail + 64, gi_c, ge_c);
+              const float dm = s.m[0], de = s.e[0]; const int dc = s.cidx[0];
+              // ---- insertions ---------------------------------------------------------------------------------------
+              const size_t colb = (size_t)f.rt(bb - 1);
+              const int kn0 = (a0 - 1 > 1) ? a0 - 1 : 1;
+              float xn[kBR];
+#pragma unroll
+              for (int u = 0; u < kBR; ++u) xn[u] = (kn0 + u <= a - 2) ? aload(&H[(size_t)f.rq(kn0 + u) * ld + colb]) : ninf;
+              float mf = ninf, ef = ninf; int cf = 0;
+              if (a0 >= 3) { mf = aload(&scr_m[r * PT + bb]); ef = aload(&scr_e[r * PT + bb]); cf = aloadi(&scr_c[r * PT + bb]); }
+              opt = clip0(prev[bb - 1] + sim, LOCAL);          // match, :447-451
+              int cat = 0;
+              const float sd = clip0(dm + sim, LOCAL);
+              if (sd > opt) { opt = sd; cat = 1; }
+              const float sfar = clip0(mf + sim, LOCAL);
+              float snear = ninf; int knear = 0;
+              float gi = gi_c, ge = ge_c;
+              if (TPOS) { const float2 t0 = tg[bb - 1], t1 = tg[bb]; gi = fminr(t0.x, t1.x); ge = fminr(t0.y, t1.y); }
+#pragma unroll
+              for (int u = 0; u < kBR; ++u) {
+                if (kn0 + u <= a - 2) {
+                  float sv = xn[u];
+                  sv -= gi + ge * (float)(a - (kn0 + u) - 2);
+                  sv += sim;
+                  sv = clip0(sv, LOCAL);
+                  if (sv > snear) { snear = sv; knear = kn0 + u; }
+                }
+              }
+              const float si = (snear > sfar) ? snear : sfar;
+              if (si > opt) { opt = si; cat = (snear > sfar) ? 3 : 2; }
+              int oa = a - 1, ob = bb - 1;
+              if (cat == 1) {
+                const bool amb = clip0(de + sim, LOCAL) == opt;
+                int k = amb ? 1 : (dc > 1 ? dc : 1);
+                const float gbi = TPOS ? tg[bb].x : 0.f, gbe = TPOS ? tg[bb].y : 0.f;
+                const float* prevF = rowsF + (size_t)((a - 1) & (kTRing - 1)) * PT;   // row a-1, every column, through L2
+                auto lit = [&](int kk, float pvv) -> float {
+                  const float2 tk = tg[kk];
+                  const float g = (TPOS ? fminr(tk.x, gbi) : gi_c) + (TPOS ? fminr(tk.y, gbe) : ge_c) * (float)(bb - kk - 2);
+                  float sv = pvv;
+                  sv -= g;
+                  sv += sim;
+                  return clip0(sv, LOCAL);
+                };
+                bool found = false;
+                if (!amb && k < kbase) {                       // the chunk lies left of the tile: its 32 sources in one batch
+                  float xs[kBC];
+#pragma unroll
+                  for (int u = 0; u < kBC; ++u) xs[u] = aload(&prevF[k + u]);
+#pragma unroll
+                  for (int u = 0; u < kBC; ++u) {
+                    if (!found && k + u >= 1 && k + u <= bb - 2 && lit(k + u, xs[u]) == opt) { found = true; ob = k + u; }
+                  }
+                  k = bb - 2;                                    // (cannot happen) nothing matched: last candidate
+                } else {
+                  for (; k < bb - 2; ++k) {
+                    const float pvv = (k >= kbase) ? prev[k] : aload(&prevF[k]);
+                    if (lit(k, pvv) == opt) break;
+                  }
+                }
+                oa = a - 1; if (!found) ob = k;
+              } else if (cat == 2) {
+                const bool amb = clip0(ef + sim, LOCAL) == opt;
+                int k = amb ? 1 : (cf > 1 ? cf : 1);
+                bool found = false;
+                if (!amb) {                                      // the chunk's 16 rows in one batch
+                  float xs[kBR];
+#pragma unroll
+                  for (int u = 0; u < kBR; ++u) xs[u] = (k + u <= a0 - 2) ? aload(&H[(size_t)f.rq(k + u) * ld + colb]) : ninf;
+#pragma unroll
+                  for (int u = 0; u < kBR; ++u) {
+                    if (!found && k + u <= a0 - 2) {
+                      float sv = xs[u];
+                      sv -= gi + ge * (float)(a - (k + u) - 2);
+                      sv += sim;
+                      sv = clip0(sv, LOCAL);
+                      if (sv == opt) { found = true; oa = k + u; }
+                    }
+                  }
+                  k = a0 - 2;
+                } else {
+                  for (; k < a0 - 2; ++k) {
+                    float sv = aload(&H[(size_t)f.rq(k) * ld + colb]);
+                    sv -= gi + ge * (float)(a - k - 2);
+                    sv += sim;
+                    sv = clip0(sv, LOCAL);
+                    if (sv == opt) break;
+                  }
+                }
+                if (!found) oa = k;
+                ob = bb - 1;
+              } else if (cat == 3) {
+                oa = knear; ob = bb - 1;
+              }
+              optp = pack_ptr(f.rq(oa), f.rt(ob));
+            }
+            if (valid) {
+              H[(size_t)i * ld + jj] = opt; P[(size_t)i * ld + jj] = optp;
+              rowF[bc] = opt;
+              curl[1 + tid] = opt;
+              const uint32_t pos = ((uint32_t)a << 16) | (uint32_t)bc;
+              if (opt > lmax || (opt == lmax && pos < lpos)) { lmax = opt; lpos = pos; }   // tiles are not visited in row-major order
+            } else {
+              curl[1 + tid] = ninf;
+            }
+          } else {
+            curl[1 + tid] = ninf;
+          }
+          if (tid == 0) curl[0] = (cb >= 1) ? aload(&rowF[kbase]) : ninf;     // column b0-1 of row a (finished in the previous tile)
+          __threadfence_block();
+          __syncthreads();
+        }
+      }
+    }
+  }
+  float m = lmax; uint32_t p = lpos;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    float om = __shfl_xor(m, o); uint32_t op = (uint32_t)__shfl_xor((int)p, o);
+    bool take = om > m || (om == m && op < p);
+    m = take ? om : m; p = take ? op : p;
+  }
+  if ((threadIdx.x & 63) == 0) { red_v[threadIdx.x >> 6] = m; red_p[threadIdx.x >> 6] = p; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kTW / 64; ++w) {
+      bool take = red_v[w] > m || (red_v[w] == m && red_p[w] < p);
+      if (take) { m = red_v[w]; p = red_p[w]; }
+    }
+    uint32_t rp = 0xFFFFFFFFu;
+    if (p != 0xFFFFFFFFu && m > 0.f) rp = ((uint32_t)f.rq((int)(p >> 16)) << 16) | (uint32_t)f.rt((int)(p & 0xFFFFu));
+    res[blockIdx.x].part_max = m;
+    res[blockIdx.x].part_pos = rp;
+  }
+}
+
 template <int NS>
 static int launch_ns(aln_batch* b, const EvalDev& proto, bool tpos, bool sub, float* scratch) {
   aln_ctx* ctx = b->ctx;
@@ -387,7 +755,10 @@ int launch_dp_exact_blocked(aln_batch* b) {
   int mx = 1;
   for (const PairDesc& d : b->h_pairs) { const int nT = d.t1 - d.t0; if (nT - 1 > mx) mx = nT - 1; }
   const int ns = mx <= 256 ? 1 : mx <= 512 ? 2 : mx <= 1024 ? 4 : 8;
-  const size_t need = blocked_scratch_floats(ns) * (size_t)b->n_pairs;
+  // templates wider than two tiles: the tiled kernel shares the far-left deletion scans between 16 rows
+  const bool tiled = mx > 2 * kTW && !getenv("ALN_EXACT_NO_TILES");
+  const int ptt = (mx + 1 <= 4 * kTW ? 4 : 8) * kTW + kBPad;          // row pitch of the scratch rows: a compile-time constant of the kernel
+  const size_t need = tiled ? (size_t)(3 * kBR + kTRing + 2) * ptt * (size_t)b->n_pairs : blocked_scratch_floats(ns) * (size_t)b->n_pairs;
   if (b->xscratch_floats < need) {
     if (b->d_xscratch) { ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); hipFree(b->d_xscratch); b->d_xscratch = nullptr; b->xscratch_floats = 0; }
     if (hipMalloc((void**)&b->d_xscratch, need * 4) != hipSuccess) { ctx->last_error = "hipMalloc (far-insertion scratch)"; return ALN_E_NOMEM; }
@@ -405,6 +776,24 @@ int launch_dp_exact_blocked(aln_batch* b) {
   const bool sub = b->sim_kind == ALN_SIM_SUBMATRIX;
   const bool tpos = b->gapdev.model == ALN_GAP_AFFINE_TPOS_MIN;
   int rc;
+  if (tiled) {
+    const size_t lds = ((size_t)2 * ptt + 2 * kTLoc + (size_t)3 * kBR * kTW) * sizeof(float);
+    const int rev = (int)(b->direction == ALN_REV);
+#define ALN_TLAUNCH(PTC, TP, LC)                                                                                                 \
+    hipLaunchKernelGGL((dp_exact_tiled_kernel<PTC, TP, LC>), dim3(b->n_pairs), dim3(kTW), lds, ctx->stream, b->d_pairs, proto,     \
+                       sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr,                        \
+                       tpos ? b->d_tge : nullptr, b->d_H, b->d_P, sub ? nullptr : b->d_S, b->d_res, rev, b->d_xscratch)
+#define ALN_TLAUNCH_P(PTC)                                                                                                       \
+    do { if (tpos) { if (b->islocal) ALN_TLAUNCH(PTC, true, true); else ALN_TLAUNCH(PTC, true, false); }                         \
+         else { if (b->islocal) ALN_TLAUNCH(PTC, false, true); else ALN_TLAUNCH(PTC, false, false); } } while (0)
+    if (ptt == 4 * kTW + kBPad) ALN_TLAUNCH_P(4 * kTW + kBPad); else ALN_TLAUNCH_P(8 * kTW + kBPad);
+#undef ALN_TLAUNCH_P
+#undef ALN_TLAUNCH
+    ALN_HIP_CHECK(ctx, hipGetLastError());
+    b->kernel_name = std::string("dp_exact_tiled_kernel<") + (tpos ? "tpos," : "const,") + (b->islocal ? "local" : "global") +
+                     (b->direction == ALN_REV ? ",rev>" : ",fwd>");
+    return ALN_OK;
+  }
   switch (ns) {
     case 1: rc = launch_ns<1>(b, proto, tpos, sub, b->d_xscratch); break;
     case 2: rc = launch_ns<2>(b, proto, tpos, sub, b->d_xscratch); break;
