@@ -28,6 +28,8 @@
 // in dp_exact.hip: per-position arrays are staged in LDS in frame order, only plane addresses see real coordinates.
 #include "aln_device.h"
 
+#include <cstdlib>
+
 namespace aln {
 
 constexpr int kBT = 256;       // threads per pair
@@ -37,6 +39,23 @@ constexpr int kBPad = 64;
 
 __device__ __forceinline__ float vmaxf(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float vminf(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// Four independent (sub, max) pairs issued as 4 subs then 4 maxes.  Left to itself the register allocator reuses one
+// temporary for every pair, which makes each v_max wait for the v_sub right before it; with only 2 waves per SIMD that
+// dependency stall is not hidden.
+__device__ __forceinline__ void submax4_vv(float& c0, float& c1, float& c2, float& c3, float x, float w0, float w1, float w2, float w3) {
+  float t0, t1, t2, t3;
+  asm("v_sub_f32 %0, %8, %9\n\tv_sub_f32 %1, %8, %10\n\tv_sub_f32 %2, %8, %11\n\tv_sub_f32 %3, %8, %12\n\t"
+      "v_max_f32 %4, %4, %0\n\tv_max_f32 %5, %5, %1\n\tv_max_f32 %6, %6, %2\n\tv_max_f32 %7, %7, %3"
+      : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+      : "v"(x), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+}
+__device__ __forceinline__ void submax4_sv(float& c0, float& c1, float& c2, float& c3, float s0, float s1, float s2, float s3, float g) {
+  float t0, t1, t2, t3;
+  asm("v_sub_f32 %0, %8, %12\n\tv_sub_f32 %1, %9, %12\n\tv_sub_f32 %2, %10, %12\n\tv_sub_f32 %3, %11, %12\n\t"
+      "v_max_f32 %4, %4, %0\n\tv_max_f32 %5, %5, %1\n\tv_max_f32 %6, %6, %2\n\tv_max_f32 %7, %7, %3"
+      : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+      : "s"(s0), "s"(s1), "s"(s2), "s"(s3), "v"(g));
+}
 // loads served by L2 (the planes are written by other threads of this workgroup; L1 lines may predate those writes)
 __device__ __forceinline__ float aload(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int aloadi(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -49,13 +68,20 @@ struct ScanState {
   int cidx[NS];
 };
 
-// k in [k0, k1) (both multiples of kBC), slots JJ..NS-1 active; MASK: slot JJ is in its triangular tail (fd < 0 = beyond b-2)
+__device__ __forceinline__ float vmax3f(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+// k in [k0, k1) (both multiples of kBC), slots JJ..NS-1 active; MASK: slot JJ is in its triangular tail (fd < 0 = beyond b-2).
+// The candidate chain (min, min, mul, add, sub, max) is evaluated STAGE by stage over several independent candidates with
+// scheduling barriers in between: written chain by chain the compiler issues each chain back to back, and with 2 waves per
+// SIMD the dependent-issue latency of those 6 instructions is what the loop then runs at.
 template <int JJ, int NS, bool TPOS, bool MASK>
 __device__ __forceinline__ void scan_range(ScanState<NS>& s, const float* __restrict__ prev, const float2* __restrict__ tg, int k0,
                                            int k1, float gi_c, float ge_c) {
   const float ninf = -__builtin_inff();
+  constexpr int NA = NS - JJ;
+  constexpr int UNR = (NS == 1) ? 2 : kBC / 4;   // one-slot kernels: a short body keeps the register count down
   for (int kc = k0; kc < k1; kc += kBC) {
-#pragma unroll
+#pragma unroll(UNR)
     for (int u4 = 0; u4 < kBC; u4 += 4) {
       const float4 p4 = *reinterpret_cast<const float4*>(prev + kc + u4);
       float4 ga = {0.f, 0.f, 0.f, 0.f}, gb = {0.f, 0.f, 0.f, 0.f};
@@ -66,18 +92,68 @@ __device__ __forceinline__ void scan_range(ScanState<NS>& s, const float* __rest
       const float pk[4] = {p4.x, p4.y, p4.z, p4.w};
       const float gik[4] = {ga.x, ga.z, gb.x, gb.z};
       const float gek[4] = {ga.y, ga.w, gb.y, gb.w};
+      if constexpr (NA >= 4) {
+        // one source column at a time, NA independent target columns per stage
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 4; ++u) {
+          float gi[NA], ge[NA];
 #pragma unroll
-        for (int j = JJ; j < NS; ++j) {
-          const float gi = TPOS ? vminf(gik[u], s.gib[j]) : gi_c;
-          const float ge = TPOS ? vminf(gek[u], s.geb[j]) : ge_c;
-          const float g = gi + ge * s.fd[j];
-          float d = pk[u] - g;
-          if (MASK && j == JJ) d = (s.fd[j] >= 0.f) ? d : ninf;
-          s.cm[j] = vmaxf(s.cm[j], d);
-          s.fd[j] -= 1.0f;
+          for (int j = 0; j < NA; ++j) {
+            gi[j] = TPOS ? vminf(gik[u], s.gib[JJ + j]) : gi_c;
+            ge[j] = TPOS ? vminf(gek[u], s.geb[JJ + j]) : ge_c;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < NA; ++j) ge[j] = ge[j] * s.fd[JJ + j];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < NA; ++j) gi[j] = gi[j] + ge[j];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < NA; ++j) gi[j] = pk[u] - gi[j];
+          if (MASK) gi[0] = (s.fd[JJ] >= 0.f) ? gi[0] : ninf;
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < NA; ++j) { s.cm[JJ + j] = vmaxf(s.cm[JJ + j], gi[j]); s.fd[JJ + j] -= 1.0f; }
+          __builtin_amdgcn_sched_barrier(0);
         }
+      } else {
+        // few target columns: the four source columns of this trip are the independent work
+        float gi[4][NA], ge[4][NA], fdu[4][NA];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < NA; ++j) {
+            gi[u][j] = TPOS ? vminf(gik[u], s.gib[JJ + j]) : gi_c;
+            ge[u][j] = TPOS ? vminf(gek[u], s.geb[JJ + j]) : ge_c;
+            fdu[u][j] = s.fd[JJ + j] - (float)u;
+          }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < NA; ++j) ge[u][j] = ge[u][j] * fdu[u][j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < NA; ++j) gi[u][j] = gi[u][j] + ge[u][j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < NA; ++j) {
+            gi[u][j] = pk[u] - gi[u][j];
+            if (MASK && j == 0) gi[u][j] = (fdu[u][j] >= 0.f) ? gi[u][j] : ninf;
+          }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+          const float a = vmax3f(s.cm[JJ + j], gi[0][j], gi[1][j]);
+          s.cm[JJ + j] = vmax3f(a, gi[2][j], gi[3][j]);
+          s.fd[JJ + j] -= 4.0f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
 #pragma unroll
@@ -177,17 +253,36 @@ __global__ __launch_bounds__(kBT, 2) void dp_exact_blocked_kernel(const PairDesc
           float fn = (float)(a0 - 2);                 // n of (row a0, k = 0); row a0+r adds r
 #pragma unroll
           for (int i = 0; i < kBR; ++i) { W[i] = gi + ge * (fn + (float)i); cm[i] = ninf; m[i] = ninf; ee[i] = ninf; cc[i] = 0; }
+          // the next chunk's 16 column values are in flight while this chunk is evaluated
+          constexpr bool PF = NS > 1;                 // the one-slot kernel has no registers to spare for the prefetch
+          float xq[kBR];
+          if (PF) {
+#pragma unroll
+            for (int u = 0; u < kBR; ++u) xq[u] = (u >= 1 && u <= a0 - 2) ? aload(&H[(size_t)f.rq(u) * ld + colb]) : ninf;
+          }
           for (int kc = 0; kc <= a0 - 2; kc += kBR) {
             float x[kBR];
+            if (PF) {
 #pragma unroll
-            for (int u = 0; u < kBR; ++u) {
-              const int k = kc + u;
-              x[u] = (k >= 1 && k <= a0 - 2) ? aload(&H[(size_t)f.rq(k) * ld + colb]) : ninf;
+              for (int u = 0; u < kBR; ++u) x[u] = xq[u];
+#pragma unroll
+              for (int u = 0; u < kBR; ++u) {
+                const int k = kc + kBR + u;
+                xq[u] = (k <= a0 - 2) ? aload(&H[(size_t)f.rq(k) * ld + colb]) : ninf;
+              }
+            } else {
+#pragma unroll
+              for (int u = 0; u < kBR; ++u) {
+                const int k = kc + u;
+                x[u] = (k >= 1 && k <= a0 - 2) ? aload(&H[(size_t)f.rq(k) * ld + colb]) : ninf;
+              }
             }
 #pragma unroll
             for (int u = 0; u < kBR; ++u) {
 #pragma unroll
-              for (int r = 0; r < kBR; ++r) cm[r] = vmaxf(cm[r], x[u] - W[(r - u) & (kBR - 1)]);
+              for (int r = 0; r < kBR; r += 4)
+                submax4_vv(cm[r], cm[r + 1], cm[r + 2], cm[r + 3], x[u], W[(r - u) & (kBR - 1)], W[(r + 1 - u) & (kBR - 1)],
+                           W[(r + 2 - u) & (kBR - 1)], W[(r + 3 - u) & (kBR - 1)]);
               fn -= 1.0f;
               W[kBR - 1 - u] = gi + ge * fn;          // G(n0 - 1) for the next k
             }
@@ -391,6 +486,19 @@ __device__ __forceinline__ void sload_rows(f4v (&dst)[NR], const float* p) {
     sload_rows<R + 1, NR, PTC>(dst, p);
   }
 }
+template <int OFF>
+__device__ __forceinline__ f2v sload2_imm(const float* p) {
+  f2v v;
+  asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(v) : "s"(p), "n"(OFF) : "memory");
+  return v;
+}
+template <int R, int NR, int PTC>
+__device__ __forceinline__ void sload_rows2(f2v (&dst)[NR], const float* p) {
+  if constexpr (R < NR) {
+    dst[R] = sload2_imm<R * PTC * 4>(p);
+    sload_rows2<R + 1, NR, PTC>(dst, p);
+  }
+}
 __device__ __forceinline__ void swait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ float vmin_sv(float s, float v) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "s"(s), "v"(v)); return r; }
 
@@ -399,19 +507,16 @@ constexpr int kTRing = 32;     // frame-ordered copies of finished rows kept per
 constexpr int kTLoc = 320;     // tile-local row buffer: 257 live entries + pads the masked tail may read
 
 template <int PT, bool TPOS, bool LOCAL>
-__global__ __launch_bounds__(kTW, 2) void dp_exact_tiled_kernel(const PairDesc* __restrict__ pairs, EvalDev proto,
+__global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* __restrict__ pairs, EvalDev proto,
                                                                  const uint8_t* __restrict__ qcodes, const uint8_t* __restrict__ tcodes,
                                                                  const float* __restrict__ tgi, const float* __restrict__ tge,
                                                                  float* __restrict__ Hbase, uint32_t* __restrict__ Pbase,
                                                                  const float* __restrict__ Sbase, PairResult* __restrict__ res, int rev,
-                                                                 float* __restrict__ scratch_base) {
+                                                                 float* __restrict__ scratch_base, int dbg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float2* tg = reinterpret_cast<float2*>(lds);          // (tgi, tge) in frame order, PT entries
   float* rowloc0 = lds + 2 * PT;                         // rows a-1 / a of the current tile, index k - kbase
   float* rowloc1 = rowloc0 + kTLoc;
-  float* fdm = rowloc1 + kTLoc;                          // far-left deletion results [kBR][kTW] (own words only)
-  float* fde = fdm + kBR * kTW;
-  int* fdc = reinterpret_cast<int*>(fde + kBR * kTW);
   __shared__ float red_v[kTW / 64];
   __shared__ uint32_t red_p[kTW / 64];
   const float ninf = -__builtin_inff();
@@ -431,11 +536,15 @@ __global__ __launch_bounds__(kTW, 2) void dp_exact_tiled_kernel(const PairDesc* 
   const int nQ = f.nQ(), nT = f.nT();
   const int tid = threadIdx.x, wave = tid >> 6;
   const float gi_c = e.gi, ge_c = e.ge;
-  // per-workgroup scratch: far-insertion results [3][kBR][PT], finished rows in frame order [kTRing][PT], (tgi, tge) [2][PT]
-  float* scr_m = scratch_base + (size_t)blockIdx.x * (size_t)(3 * kBR + kTRing + 2) * PT;
+  // per-workgroup scratch: far-insertion and far-left-deletion results [2][3][kBR][PT] (own words only, read back through L2),
+  // finished rows in frame order [kTRing][PT], (tgi, tge) [2][PT]
+  float* scr_m = scratch_base + (size_t)blockIdx.x * (size_t)(6 * kBR + kTRing + 2) * PT;
   float* scr_e = scr_m + kBR * PT;
   int* scr_c = reinterpret_cast<int*>(scr_e + kBR * PT);
-  float* rowsF = scr_m + 3 * kBR * PT;
+  float* fdm = scr_m + 3 * kBR * PT;
+  float* fde = fdm + kBR * PT;
+  int* fdc = reinterpret_cast<int*>(fde + kBR * PT);
+  float* rowsF = scr_m + 6 * kBR * PT;
   float* tgiF = rowsF + kTRing * PT;
   float* tgeF = tgiF + PT;
 
@@ -467,36 +576,44 @@ __global__ __launch_bounds__(kTW, 2) void dp_exact_tiled_kernel(const PairDesc* 
           float gi = gi_c, ge = ge_c;
           if (TPOS) { const float2 t0 = tg[b - 1], t1 = tg[b]; gi = fminr(t0.x, t1.x); ge = fminr(t0.y, t1.y); }
           const size_t colb = (size_t)f.rt(b - 1);
-          float W[kBR], cm[kBR], m[kBR], ee[kBR]; int cc[kBR];
-          float fn = (float)(a0 - 2);
+          constexpr int HW = kBR / 2;                  // two 8-row windows: half the registers of one 16-row window
+#pragma unroll 1
+          for (int h = 0; h < 2; ++h) {
+            float W[HW], cm[HW], m[HW], ee[HW]; int cc[HW];
+            float fn = (float)(a0 + HW * h - 2);       // n of (row a0 + 8h, k = 0)
 #pragma unroll
-          for (int i = 0; i < kBR; ++i) { W[i] = gi + ge * (fn + (float)i); cm[i] = ninf; m[i] = ninf; ee[i] = ninf; cc[i] = 0; }
-          for (int kc = 0; kc <= a0 - 2; kc += kBR) {
-            float x[kBR];
+            for (int i = 0; i < HW; ++i) { W[i] = gi + ge * (fn + (float)i); cm[i] = ninf; m[i] = ninf; ee[i] = ninf; cc[i] = 0; }
+            for (int kc = 0; kc <= ((dbg & 2) ? -1 : a0 - 2); kc += kBR) {
+              float x[kBR];
 #pragma unroll
-            for (int u = 0; u < kBR; ++u) {
-              const int k = kc + u;
-              x[u] = (k >= 1 && k <= a0 - 2) ? aload(&H[(size_t)f.rq(k) * ld + colb]) : ninf;
+              for (int u = 0; u < kBR; ++u) {
+                const int k = kc + u;
+                x[u] = (k >= 1 && k <= a0 - 2) ? aload(&H[(size_t)f.rq(k) * ld + colb]) : ninf;
+              }
+#pragma unroll
+              for (int u = 0; u < kBR; ++u) {
+#pragma unroll
+                for (int r = 0; r < HW; r += 4)
+                  submax4_vv(cm[r], cm[r + 1], cm[r + 2], cm[r + 3], x[u], W[(r - u) & (HW - 1)], W[(r + 1 - u) & (HW - 1)],
+                             W[(r + 2 - u) & (HW - 1)], W[(r + 3 - u) & (HW - 1)]);
+                fn -= 1.0f;
+                W[(HW - 1 - u) & (HW - 1)] = gi + ge * fn;
+              }
+#pragma unroll
+              for (int r = 0; r < HW; ++r) {
+                const bool up = cm[r] > m[r];
+                ee[r] = up ? m[r] : ee[r];
+                cc[r] = up ? kc : cc[r];
+                m[r] = up ? cm[r] : m[r];
+                cm[r] = ninf;
+              }
             }
+            if (bv && bc >= 2) {
 #pragma unroll
-            for (int u = 0; u < kBR; ++u) {
-#pragma unroll
-              for (int r = 0; r < kBR; ++r) cm[r] = vmaxf(cm[r], x[u] - W[(r - u) & (kBR - 1)]);
-              fn -= 1.0f;
-              W[kBR - 1 - u] = gi + ge * fn;
+              for (int r = 0; r < HW; ++r) {
+                scr_m[(HW * h + r) * PT + bc] = m[r]; scr_e[(HW * h + r) * PT + bc] = ee[r]; scr_c[(HW * h + r) * PT + bc] = cc[r];
+              }
             }
-#pragma unroll
-            for (int r = 0; r < kBR; ++r) {
-              const bool up = cm[r] > m[r];
-              ee[r] = up ? m[r] : ee[r];
-              cc[r] = up ? kc : cc[r];
-              m[r] = up ? cm[r] : m[r];
-              cm[r] = ninf;
-            }
-          }
-          if (bv && bc >= 2) {
-#pragma unroll
-            for (int r = 0; r < kBR; ++r) { scr_m[r * PT + bc] = m[r]; scr_e[r * PT + bc] = ee[r]; scr_c[r * PT + bc] = cc[r]; }
           }
         }
         // ============ far-left deletions: sources k = 1 .. kbase-1 of rows a0-1 .. a0+14, shared gap values ===========
@@ -511,7 +628,9 @@ __global__ __launch_bounds__(kTW, 2) void dp_exact_tiled_kernel(const PairDesc* 
           for (int r = 0; r < kBR; ++r) { cm[r] = ninf; m[r] = ninf; ee[r] = ninf; cc[r] = 0; }
           // source row of target row a0+r is a0+r-1: ring slots (a0-1) & 31 + r — consecutive, because a0-1 is a multiple of 16
           const float* sbase = rowsF + (size_t)((a0 - 1) & (kTRing - 1)) * PT;
-          for (int kc = 0; kc < kbase; kc += kBC) {
+          // 4 source columns x 16 rows per trip: 18 scalar loads, one wait, 148 VALU instructions.  (Double-buffering the
+          // SGPRs was tried: under the kernel's SGPR pressure the compiler copies the in-flight registers and waits early.)
+          for (int kc = 0; kc < ((dbg & 1) ? 0 : kbase); kc += kBC) {
 #pragma unroll 1
             for (int k = kc; k < kc + kBC; k += 4) {
               f4v src[kBR];
@@ -527,7 +646,8 @@ __global__ __launch_bounds__(kTW, 2) void dp_exact_tiled_kernel(const PairDesc* 
                 fd -= 1.0f;
                 if (k + u == 0) continue;              // column 0 is never a source (dpmatrix.h:459 starts at t0+1)
 #pragma unroll
-                for (int r = 0; r < kBR; ++r) cm[r] = vmaxf(cm[r], src[r][u] - g);
+                for (int r = 0; r < kBR; r += 4)
+                  submax4_sv(cm[r], cm[r + 1], cm[r + 2], cm[r + 3], src[r][u], src[r + 1][u], src[r + 2][u], src[r + 3][u], g);
               }
             }
 #pragma unroll
@@ -540,7 +660,7 @@ __global__ __launch_bounds__(kTW, 2) void dp_exact_tiled_kernel(const PairDesc* 
             }
           }
 #pragma unroll
-          for (int r = 0; r < kBR; ++r) { fdm[r * kTW + tid] = m[r]; fde[r * kTW + tid] = ee[r]; fdc[r * kTW + tid] = cc[r]; }
+          for (int r = 0; r < kBR; ++r) { fdm[r * PT + bc] = m[r]; fde[r * PT + bc] = ee[r]; fdc[r * PT + bc] = cc[r]; }
         }
         // ============ tile prologue: row a0-1 of the tile's columns (and column b0-1) into the local buffer ==========
         {
@@ -584,11 +704,13 @@ __global__ __launch_bounds__(kTW, 2) void dp_exact_tiled_kernel(const PairDesc* 
               if (TPOS) { const float2 t = tg[bb]; s.gib[0] = t.x; s.geb[0] = t.y; } else { s.gib[0] = 0.f; s.geb[0] = 0.f; }
               s.fd[0] = (float)(bb - kbase - 2);
               s.cm[0] = ninf;
-              if (cb >= 1) { s.m[0] = fdm[r * kTW + tid]; s.e[0] = fde[r * kTW + tid]; s.cidx[0] = fdc[r * kTW + tid]; }
+              if (cb >= 1) { s.m[0] = aload(&fdm[r * PT + bb]); s.e[0] = aload(&fde[r * PT + bb]); s.cidx[0] = aloadi(&fdc[r * PT + bb]); }
               else { s.m[0] = ninf; s.e[0] = ninf; s.cidx[0] = 0; }
               const int tail = kbase + 64 * wave;
-              scan_range<0, 1, TPOS, false>(s, prev, tg, kbase, tail, gi_c, ge_c);
-              scan_range<0, 1, TPOS, true>(s, prev, tg, tail, tail + 64, gi_c, ge_c);
+              if (!(dbg & 4)) {
+                scan_range<0, 1, TPOS, false>(s, prev, tg, kbase, tail, gi_c, ge_c);
+                scan_range<0, 1, TPOS, true>(s, prev, tg, tail, tail + 64, gi_c, ge_c);
+              }
               const float dm = s.m[0], de = s.e[0]; const int dc = s.cidx[0];
               // ---- insertions ---------------------------------------------------------------------------------------
               const size_t colb = (size_t)f.rt(bb - 1);
@@ -619,6 +741,7 @@ __global__ __launch_bounds__(kTW, 2) void dp_exact_tiled_kernel(const PairDesc* 
               const float si = (snear > sfar) ? snear : sfar;
               if (si > opt) { opt = si; cat = (snear > sfar) ? 3 : 2; }
               int oa = a - 1, ob = bb - 1;
+              if (dbg & 8) cat = 0;
               if (cat == 1) {
                 const bool amb = clip0(de + sim, LOCAL) == opt;
                 int k = amb ? 1 : (dc > 1 ? dc : 1);
@@ -758,7 +881,7 @@ int launch_dp_exact_blocked(aln_batch* b) {
   // templates wider than two tiles: the tiled kernel shares the far-left deletion scans between 16 rows
   const bool tiled = mx > 2 * kTW && !getenv("ALN_EXACT_NO_TILES");
   const int ptt = (mx + 1 <= 4 * kTW ? 4 : 8) * kTW + kBPad;          // row pitch of the scratch rows: a compile-time constant of the kernel
-  const size_t need = tiled ? (size_t)(3 * kBR + kTRing + 2) * ptt * (size_t)b->n_pairs : blocked_scratch_floats(ns) * (size_t)b->n_pairs;
+  const size_t need = tiled ? (size_t)(6 * kBR + kTRing + 2) * ptt * (size_t)b->n_pairs : blocked_scratch_floats(ns) * (size_t)b->n_pairs;
   if (b->xscratch_floats < need) {
     if (b->d_xscratch) { ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); hipFree(b->d_xscratch); b->d_xscratch = nullptr; b->xscratch_floats = 0; }
     if (hipMalloc((void**)&b->d_xscratch, need * 4) != hipSuccess) { ctx->last_error = "hipMalloc (far-insertion scratch)"; return ALN_E_NOMEM; }
@@ -777,12 +900,13 @@ int launch_dp_exact_blocked(aln_batch* b) {
   const bool tpos = b->gapdev.model == ALN_GAP_AFFINE_TPOS_MIN;
   int rc;
   if (tiled) {
-    const size_t lds = ((size_t)2 * ptt + 2 * kTLoc + (size_t)3 * kBR * kTW) * sizeof(float);
+    const size_t lds = ((size_t)2 * ptt + 2 * kTLoc) * sizeof(float);
     const int rev = (int)(b->direction == ALN_REV);
+    const int dbg = getenv("ALN_TILED_DEBUG_SKIP") ? atoi(getenv("ALN_TILED_DEBUG_SKIP")) : 0;   // timing experiments only: results are wrong
 #define ALN_TLAUNCH(PTC, TP, LC)                                                                                                 \
     hipLaunchKernelGGL((dp_exact_tiled_kernel<PTC, TP, LC>), dim3(b->n_pairs), dim3(kTW), lds, ctx->stream, b->d_pairs, proto,     \
                        sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr,                        \
-                       tpos ? b->d_tge : nullptr, b->d_H, b->d_P, sub ? nullptr : b->d_S, b->d_res, rev, b->d_xscratch)
+                       tpos ? b->d_tge : nullptr, b->d_H, b->d_P, sub ? nullptr : b->d_S, b->d_res, rev, b->d_xscratch, dbg)
 #define ALN_TLAUNCH_P(PTC)                                                                                                       \
     do { if (tpos) { if (b->islocal) ALN_TLAUNCH(PTC, true, true); else ALN_TLAUNCH(PTC, true, false); }                         \
          else { if (b->islocal) ALN_TLAUNCH(PTC, false, true); else ALN_TLAUNCH(PTC, false, false); } } while (0)
