@@ -124,7 +124,8 @@ __global__ __launch_bounds__(kExactThreads) void dp_exact_kernel(const PairDesc*
 
 int launch_dp_exact(aln_batch* b) {
   aln_ctx* ctx = b->ctx;
-  // same results, restructured scans (dp_exact_blocked.hip); this literal kernel stays for templates beyond 2049 columns
+  // same results, restructured scans (dp_exact_blocked.hip); this literal kernel stays for templates beyond 4096 columns
+  // and for the table gap model
   if (dp_exact_blocked_legal(b) && !getenv("ALN_EXACT_LITERAL")) return launch_dp_exact_blocked(b);
   // untouched cells read score 0 / pointer (-1,-1) (dpmatrix.cpp:17-25): the kernel only writes computed cells
   ALN_HIP_CHECK(ctx, hipMemsetAsync(b->d_H, 0, (size_t)b->plane_elems * 4, ctx->stream));

@@ -870,7 +870,7 @@ static size_t blocked_scratch_floats(int ns) { return (size_t)3 * kBR * (ns * 25
 bool dp_exact_blocked_legal(const aln_batch* b) {
   int mx = 0;
   for (const PairDesc& d : b->h_pairs) { const int nT = d.t1 - d.t0; if (nT - 1 > mx) mx = nT - 1; }
-  return mx <= 8 * 256 && b->gapdev.model != ALN_GAP_DEL_TABLE_INS_TPOS;   // the table model runs in the literal kernel
+  return mx <= 16 * 256 && b->gapdev.model != ALN_GAP_DEL_TABLE_INS_TPOS;   // the table model runs in the literal kernel
 }
 
 int launch_dp_exact_blocked(aln_batch* b) {
@@ -879,8 +879,8 @@ int launch_dp_exact_blocked(aln_batch* b) {
   for (const PairDesc& d : b->h_pairs) { const int nT = d.t1 - d.t0; if (nT - 1 > mx) mx = nT - 1; }
   const int ns = mx <= 256 ? 1 : mx <= 512 ? 2 : mx <= 1024 ? 4 : 8;
   // templates wider than two tiles: the tiled kernel shares the far-left deletion scans between 16 rows
-  const bool tiled = mx > 2 * kTW && !getenv("ALN_EXACT_NO_TILES");
-  const int ptt = (mx + 1 <= 4 * kTW ? 4 : 8) * kTW + kBPad;          // row pitch of the scratch rows: a compile-time constant of the kernel
+  const bool tiled = mx > 2 * kTW && (!getenv("ALN_EXACT_NO_TILES") || mx > 8 * kTW);   // the slot kernel ends at 8 x 256 columns
+  const int ptt = (mx + 1 <= 4 * kTW ? 4 : mx + 1 <= 8 * kTW ? 8 : mx + 1 <= 12 * kTW ? 12 : 16) * kTW + kBPad;          // row pitch of the scratch rows: a compile-time constant of the kernel
   const size_t need = tiled ? (size_t)(6 * kBR + kTRing + 2) * ptt * (size_t)b->n_pairs : blocked_scratch_floats(ns) * (size_t)b->n_pairs;
   if (b->xscratch_floats < need) {
     if (b->d_xscratch) { ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); hipFree(b->d_xscratch); b->d_xscratch = nullptr; b->xscratch_floats = 0; }
@@ -910,7 +910,10 @@ int launch_dp_exact_blocked(aln_batch* b) {
 #define ALN_TLAUNCH_P(PTC)                                                                                                       \
     do { if (tpos) { if (b->islocal) ALN_TLAUNCH(PTC, true, true); else ALN_TLAUNCH(PTC, true, false); }                         \
          else { if (b->islocal) ALN_TLAUNCH(PTC, false, true); else ALN_TLAUNCH(PTC, false, false); } } while (0)
-    if (ptt == 4 * kTW + kBPad) ALN_TLAUNCH_P(4 * kTW + kBPad); else ALN_TLAUNCH_P(8 * kTW + kBPad);
+    if (ptt == 4 * kTW + kBPad) ALN_TLAUNCH_P(4 * kTW + kBPad);
+    else if (ptt == 8 * kTW + kBPad) ALN_TLAUNCH_P(8 * kTW + kBPad);
+    else if (ptt == 12 * kTW + kBPad) ALN_TLAUNCH_P(12 * kTW + kBPad);
+    else ALN_TLAUNCH_P(16 * kTW + kBPad);
 #undef ALN_TLAUNCH_P
 #undef ALN_TLAUNCH
     ALN_HIP_CHECK(ctx, hipGetLastError());

@@ -294,7 +294,7 @@ def test_blocked_exact_kernel_long_rows(direction, blosum62):
     alpha, table = blosum62
     d = DIRS[direction]
     od = orc.FWD if direction == "fwd" else orc.REV
-    shapes = [(70, 300), (40, 700), (350, 90), (45, 1100), (60, 2040)]
+    shapes = [(70, 300), (40, 700), (350, 90), (45, 1100), (60, 2040), (33, 3000), (37, 4090)]
     pairs = []
     for n, (ql, tl) in enumerate(shapes):
         q, t = homolog_pair(81000 + n, max(ql, tl), sub_rate=0.3, indel=5)
@@ -312,7 +312,7 @@ def test_blocked_exact_kernel_long_rows(direction, blosum62):
         b.close()
     # fractional planes + position-dependent gaps
     rng = np.random.RandomState(11)
-    dims = [(50, 600), (300, 1500), (37, 2050)]
+    dims = [(50, 600), (300, 1500), (37, 2050), (35, 3300)]
     planes, tgis, tges = [], [], []
     for (Q, T) in dims:
         S = rng.normal(-0.12, 1.0, size=(Q, T)).astype(np.float32)
