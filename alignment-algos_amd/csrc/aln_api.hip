@@ -271,6 +271,7 @@ int upload_tgaps(aln_batch* b, const aln_gap* gap) {
 
 int run_dp(aln_batch* b, bool simplane_integral) {
   aln_ctx* ctx = b->ctx;
+  if (b->n_pairs == 0) { b->have_dp = true; b->kernel_name = "(empty batch)"; return ALN_OK; }   // nothing to launch
   const bool sub = b->sim_kind == ALN_SIM_SUBMATRIX;
   bool fast = false, tagged = false;
   if (b->algo != ALN_DP_EXACT && !b->have_sub && b->direction == ALN_FWD) {
@@ -364,6 +365,7 @@ int aln_batch_dp_sub(aln_batch* b, const aln_sim* sim, const aln_gap* gap, int32
 int aln_batch_last_dp_ms(aln_batch* b, float* ms) {
   if (!b || !ms) return ALN_E_ARG;
   if (!b->have_dp) return ALN_E_STATE;
+  if (b->n_pairs == 0) { *ms = 0.f; return ALN_OK; }
   ALN_HIP_CHECK(b->ctx, hipEventSynchronize(b->ev1));
   ALN_HIP_CHECK(b->ctx, hipEventElapsedTime(ms, b->ev0, b->ev1));
   return ALN_OK;
@@ -436,6 +438,7 @@ int aln_batch_get_sim(aln_batch* b, int32_t pair, float* sim) {
 int aln_batch_get_corner_scores(aln_batch* b, float* scores) {
   if (!b || !scores) return ALN_E_ARG;
   if (!b->have_dp) return ALN_E_STATE;
+  if (b->n_pairs == 0) return ALN_OK;
   std::vector<PairResult> r(b->n_pairs);
   ALN_HIP_CHECK(b->ctx, hipMemcpyAsync(r.data(), b->d_res, sizeof(PairResult) * b->n_pairs, hipMemcpyDeviceToHost, b->ctx->stream));
   ALN_HIP_CHECK(b->ctx, hipStreamSynchronize(b->ctx->stream));
@@ -477,6 +480,7 @@ static int fetch_paths(aln_batch* b, float* scores, int32_t* n, int32_t* pairs, 
 int aln_batch_optimal(aln_batch* b, float* scores, int32_t* n, int32_t* pairs, int32_t pair_stride, int32_t* status) {
   if (!b) return ALN_E_ARG;
   if (!b->have_dp || b->have_sub) return ALN_E_STATE;
+  if (b->n_pairs == 0) return ALN_OK;
   int rc = launch_traceback(b, false);
   if (rc) return rc;
   return fetch_paths(b, scores, n, pairs, pair_stride, status, !b->islocal, b->direction == ALN_FWD);
@@ -485,6 +489,7 @@ int aln_batch_optimal(aln_batch* b, float* scores, int32_t* n, int32_t* pairs, i
 int aln_batch_optimal_subali(aln_batch* b, float* scores, int32_t* n, int32_t* pairs, int32_t pair_stride, int32_t* status) {
   if (!b) return ALN_E_ARG;
   if (!b->have_dp || !b->have_sub) return ALN_E_STATE;
+  if (b->n_pairs == 0) return ALN_OK;
   int rc = launch_traceback(b, true);
   if (rc) return rc;
   return fetch_paths(b, scores, n, pairs, pair_stride, status, true, true);

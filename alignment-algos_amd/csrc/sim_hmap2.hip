@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256) void hmap2_apply_kernel(const PairDesc* __rest
 int launch_sim_hmap2(aln_batch* b, const aln_sim* sim) {
   aln_ctx* ctx = b->ctx;
   if (!sim->q_prof.aa || !sim->q_prof.sse || !sim->q_prof.conf || !sim->t_prof.aa || !sim->t_prof.sse || !sim->t_prof.conf) return ALN_E_ARG;
+  if (b->n_pairs == 0) return ALN_OK;
   if (!b->d_S) ALN_HIP_CHECK(ctx, hipMalloc((void**)&b->d_S, (size_t)std::max<int64_t>(b->plane_elems, 1) * 4));
   float *dq_aa = nullptr, *dq_sse = nullptr, *dq_conf = nullptr, *dt_aa = nullptr, *dt_sse = nullptr, *dt_conf = nullptr, *d_stats = nullptr;
   auto cleanup = [&]() { hipFree(dq_aa); hipFree(dq_sse); hipFree(dq_conf); hipFree(dt_aa); hipFree(dt_sse); hipFree(dt_conf); hipFree(d_stats); };

@@ -433,3 +433,60 @@ def test_gn2_table_gap_model(direction):
                     assert np.float32(g["score"]).view(np.uint32) == r["score"].view(np.uint32), (p, mode, k)
                     assert np.array_equal(g["pairs"], r["pairs"])
         b.close()
+
+
+def test_edge_sizes(blosum62):
+    """Empty batch, empty sequences (only '^$'), 1-residue sequences against the longest a kernel takes, and the exact
+    maximum sizes of the tagged kernel (2048 x 2048 including sentinels) — against the oracle where it is fast enough,
+    otherwise against the other kernels."""
+    alpha, table = blosum62
+    # empty batch: every call is a no-op
+    b = aln_amd.Batch(gpu_util.ctx(), [], [])
+    b.dp_submatrix(alpha, table, 3, 11, 1)
+    sc, lists, status = b.optimal()
+    assert len(sc) == 0 and len(lists) == 0
+    b.close()
+    # empty and tiny sequences in one ragged batch, every align_t, both gap kinds
+    g = MT19937(424242)
+    long_t = residues(g, 2046)
+    qs = ["", "", "A", "W", long_t[:5], ""]
+    ts = ["", "ACD", "", long_t, "W", long_t]
+    for mode in range(5):
+        for gi, ge in ((11, 1), (4.73, 0.34)):
+            b = aln_amd.Batch(gpu_util.ctx(), qs, ts)
+            b.dp_submatrix(alpha, table, mode, gi, ge)
+            scores, lists, status = b.optimal()
+            for p, (q, t) in enumerate(zip(qs, ts)):
+                S = orc.sim_submatrix(q, t, alpha, table)
+                rc, D0, PQ0, PT0 = orc.dp_build(S, orc.Gap(mode, gi, ge))
+                D, PQ, PT = b.get_cells(p)
+                assert np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (mode, gi, p)
+                assert np.array_equal(PQ, PQ0) and np.array_equal(PT, PT0), (mode, gi, p)
+                rc2, sc, pairs = orc.optimal(D0, PQ0, PT0, mode == 3)
+                assert status[p] == rc2, (mode, gi, p, status[p], rc2)
+                if rc2 == 0:
+                    assert np.float32(scores[p]).view(np.uint32) == sc.view(np.uint32) and np.array_equal(lists[p], pairs)
+            b.close()
+    # the tagged kernel's largest matrix: 2046 residues each
+    q, t = homolog_pair(77001, 2046)
+    planes = {}
+    for name, env, algo in (("tag", None, aln_amd.DP_FAST), ("exact", None, aln_amd.DP_EXACT)):
+        b = aln_amd.Batch(gpu_util.ctx(), [q], [t])
+        b.dp_submatrix(alpha, table, 3, 11, 1, aln_amd.FWD, algo)
+        planes[name] = (b.kernel_name(), b.get_cells(0), b.optimal())
+        b.close()
+    assert "dp_affine_tag" in planes["tag"][0] and "dp_exact_tiled" in planes["exact"][0]
+    for a, c in zip(planes["tag"][1], planes["exact"][1]):
+        assert np.array_equal(np.asarray(a).view(np.uint32), np.asarray(c).view(np.uint32))
+    assert np.array_equal(planes["tag"][2][1][0], planes["exact"][2][1][0])
+    # one residue more is beyond the tagged kernel: the int kernel takes over, same planes as the exact kernel
+    q2, t2 = q + "A", t + "C"
+    res = []
+    for algo in (aln_amd.DP_FAST, aln_amd.DP_EXACT):
+        b = aln_amd.Batch(gpu_util.ctx(), [q2], [t2])
+        b.dp_submatrix(alpha, table, 3, 11, 1, aln_amd.FWD, algo)
+        res.append((b.kernel_name(), b.get_cells(0)))
+        b.close()
+    assert "dp_affine_int" in res[0][0], res[0][0]
+    for a, c in zip(res[0][1], res[1][1]):
+        assert np.array_equal(np.asarray(a).view(np.uint32), np.asarray(c).view(np.uint32))
