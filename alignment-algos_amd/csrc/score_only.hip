@@ -60,7 +60,7 @@ __global__ __launch_bounds__(64) void score_local_kernel(ScoreArgs a) {
   const int cb = 4 * lane;
   const int gime = gi - ge;
 
-  int code4[R][4], gec[R][4];
+  int code4[R][4], gec[R][4], ekc[R][4], inm[R][4];
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -70,8 +70,10 @@ __global__ __launch_bounds__(64) void score_local_kernel(ScoreArgs a) {
       if (c < T) code = tc[c];
       code4[r][x] = code * 4;
       gec[r][x] = ge * c;
+      ekc[r][x] = ge * c + gime;                                      // E(c+1) = prefix max - ekc
+      inm[r][x] = ((unsigned)(c - 1) < (unsigned)(T - 2)) ? -1 : 0;   // interior column: scores are >= 0, so "& mask" zeroes the rest
     }
-  int d[R][4], gmx[R][4], cv[R];
+  int d[R][4], gmx[R][4], cv[R], ak[R][4];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     cv[r] = kNegS;
@@ -92,9 +94,11 @@ __global__ __launch_bounds__(64) void score_local_kernel(ScoreArgs a) {
       for (int x = 0; x < 4; ++x) {
         int A = d[r][x] + gec[r][x];
         if (r == 0 && x == 0) A = (lane == 0) ? kNegS : A;   // column 0 is never a source
+        ak[r][x] = A;
         tk = max(tk, A);
-        lmax = max(lmax, d[r][x]);
       }
+      lmax = max(max(lmax, d[r][0]), d[r][1]);               // two v_max3 per group
+      lmax = max(max(lmax, d[r][2]), d[r][3]);
       const int ik = wave_incl_max_s(tk);
       const int ek = sdpp<0x138>(kNegS, ik);
       cv[r] = max(sk, ek);
@@ -110,7 +114,8 @@ __global__ __launch_bounds__(64) void score_local_kernel(ScoreArgs a) {
       for (int x = 0; x < 4; ++x) {
         const int c = cb + 256 * r + x;
         const int h = max(tab_at(qrow, code4[r][x]), 0);
-        d[r][x] = ((unsigned)(c - 1) < (unsigned)(T - 2)) ? h : 0;
+        d[r][x] = h & inm[r][x];
+        (void)c;
       }
     finish_row();
   }
@@ -127,9 +132,8 @@ __global__ __launch_bounds__(64) void score_local_kernel(ScoreArgs a) {
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
         const int m = d[r][x];
-        int A = m + gec[r][x];
-        if (r == 0 && x == 0) A = (lane == 0) ? kNegS : A;
-        const int e = pv - gec[r][x] - gime;
+        const int A = ak[r][x];
+        const int e = pv - ekc[r][x];
         const int f = gmx[r][x] - roff;
         bk[r][x] = max(max(m, e), f);
         pv = max(pv, A);
@@ -148,11 +152,8 @@ __global__ __launch_bounds__(64) void score_local_kernel(ScoreArgs a) {
         const int c = cb + 256 * r + x;
         const int s = tab_at(qrow, code4[r][x]);
         int h = max(((x == 0) ? uk : bk[r][x - 1]) + s, 0);
-        if (masked) {
-          const int h1 = max(s, 0);                          // column 1: free insertion from the origin (:593-599)
-          h = (c == 1) ? h1 : h;
-          h = ((unsigned)(c - 1) < (unsigned)(T - 2)) ? h : 0;
-        }
+        if (r == 0 && x == 1) h = (c == 1) ? max(s, 0) : h;  // column 1 (lane 0 only): free insertion from the origin (:593-599)
+        if (masked) h &= inm[r][x];                          // columns 0 and >= T-1 stay 0
         d[r][x] = h;
       }
     }
