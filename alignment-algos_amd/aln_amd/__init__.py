@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libalnhip.so")
 
 GLOBAL_LOCAL, GLOBAL, LOCAL_GLOBAL, LOCAL, SEMI_LOCAL = 0, 1, 2, 3, 4
 FWD, REV = 1, 2
-GAP_AFFINE_CONST, GAP_AFFINE_TPOS_MIN, GAP_DEL_TABLE_INS_TPOS = 0, 1, 2
+GAP_AFFINE_CONST, GAP_AFFINE_TPOS_MIN, GAP_DEL_TABLE_INS_TPOS, GAP_TABLES = 0, 1, 2, 3
 SIM_SUBMATRIX, SIM_MATRIX, SIM_HMAP2 = 0, 1, 2
 DP_AUTO, DP_EXACT, DP_FAST = 0, 1, 2
 ENUM_CW, ENUM_UCW = 0, 1
@@ -42,7 +42,7 @@ class AlnProfiles(C.Structure):
 class AlnGap(C.Structure):
     _fields_ = [("model", C.c_int32), ("align_type", C.c_int32), ("gap_init", C.c_float), ("gap_extn", C.c_float),
                 ("t_gap_init", _fp), ("t_gap_extn", _fp), ("dp_local", C.c_int32), ("t_gap_cn", _fp), ("del_table", _fp),
-                ("del_table_off", _lp)]
+                ("del_table_off", _lp), ("ins_tables", _fp), ("ins_table_off", _lp)]
 
 
 class AlnSim(C.Structure):
@@ -227,12 +227,25 @@ class Batch:
         return len(self.qpool.seqs[self.q_idx[p]]), len(self.tpool.seqs[self.t_idx[p]])
 
     # --- DP ---------------------------------------------------------------------------------
-    def _gap(self, align_type, gi, ge, tgi=None, tge=None, tcn=None, del_tables=None):
+    def _gap(self, align_type, gi, ge, tgi=None, tge=None, tcn=None, del_tables=None, ins_tables=None):
         g = AlnGap()
         g.align_type = int(align_type)
         g.gap_init = float(np.float32(gi))
         g.gap_extn = float(np.float32(ge))
-        if del_tables is not None:
+        if ins_tables is not None:
+            # fully tabulated gap functions: one T x T deletion table per template sequence, three T x Q insertion planes per pair
+            g.model = GAP_TABLES
+            dflat = [np.ascontiguousarray(t, dtype=np.float32).reshape(-1) for t in del_tables]
+            doff = np.zeros(len(dflat), dtype=np.int64)
+            doff[1:] = np.cumsum([len(t) for t in dflat])[:-1]
+            iflat = [np.ascontiguousarray(t, dtype=np.float32).reshape(-1) for t in ins_tables]
+            ioff = np.zeros(len(iflat), dtype=np.int64)
+            ioff[1:] = np.cumsum([len(t) for t in iflat])[:-1]
+            dblob, iblob = np.concatenate(dflat), np.concatenate(iflat)
+            self._keep += [dblob, doff, iblob, ioff]
+            g.del_table, g.del_table_off = _f(dblob), doff.ctypes.data_as(_lp)
+            g.ins_tables, g.ins_table_off = _f(iblob), ioff.ctypes.data_as(_lp)
+        elif del_tables is not None:
             # Gn2Eval model: v_gi / v_ge / v_cn over the template pool + one T x T deletion table per template sequence
             g.model = GAP_DEL_TABLE_INS_TPOS
             a, b, c = (np.ascontiguousarray(x, dtype=np.float32) for x in (tgi, tge, tcn))
@@ -263,7 +276,7 @@ class Batch:
         _check(lib().aln_batch_dp(self.h, C.byref(s), C.byref(g), direction, algo, int(bug_b4)), self.ctx.h)
 
     def dp_simmatrix(self, planes, align_type, gi, ge, direction=FWD, algo=DP_AUTO, bug_b4=False, tgi=None, tge=None, tcn=None,
-                     del_tables=None):
+                     del_tables=None, ins_tables=None):
         """planes: list of Q x T float32 arrays, one per pair."""
         flat = [np.ascontiguousarray(p, dtype=np.float32).reshape(-1) for p in planes]
         off = np.zeros(len(flat) + 1, dtype=np.int64)
@@ -273,7 +286,7 @@ class Batch:
         s.kind = SIM_MATRIX
         s.planes = _f(blob)
         s.plane_off = off.ctypes.data_as(_lp)
-        g = self._gap(align_type, gi, ge, tgi, tge, tcn, del_tables)
+        g = self._gap(align_type, gi, ge, tgi, tge, tcn, del_tables, ins_tables)
         _check(lib().aln_batch_dp(self.h, C.byref(s), C.byref(g), direction, algo, int(bug_b4)), self.ctx.h)
 
     def dp_sub_submatrix(self, alphabet, table, align_type, gi, ge, direction, bounds):

@@ -145,7 +145,7 @@ void aln_batch_destroy(aln_batch* b) {
   if (!b) return;
   hipFree(b->d_pairs); hipFree(b->d_qcodes); hipFree(b->d_tcodes); hipFree(b->d_H); hipFree(b->d_P); hipFree(b->d_S);
   hipFree(b->d_res); hipFree(b->d_table32); hipFree(b->d_tablef); hipFree(b->d_tgi); hipFree(b->d_tge);
-  hipFree(b->d_path); hipFree(b->d_bounds); hipFree(b->d_xscratch); hipFree(b->d_tcn); hipFree(b->d_deltab); hipFree(b->d_deltab_off);
+  hipFree(b->d_path); hipFree(b->d_bounds); hipFree(b->d_xscratch); hipFree(b->d_tcn); hipFree(b->d_deltab); hipFree(b->d_deltab_off); hipFree(b->d_instab);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
   delete b;
@@ -236,14 +236,17 @@ int upload_simplanes(aln_batch* b, const aln_sim* sim, bool* integral) {
 
 int upload_tgaps(aln_batch* b, const aln_gap* gap) {
   aln_ctx* ctx = b->ctx;
-  if (!gap->t_gap_init || !gap->t_gap_extn) return ALN_E_ARG;
-  if (!b->d_tgi) { int rc = dalloc(ctx, &b->d_tgi, (size_t)b->t_total); if (rc) return rc; }
-  if (!b->d_tge) { int rc = dalloc(ctx, &b->d_tge, (size_t)b->t_total); if (rc) return rc; }
-  ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_tgi, gap->t_gap_init, b->t_total * 4, hipMemcpyHostToDevice, ctx->stream));
-  ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_tge, gap->t_gap_extn, b->t_total * 4, hipMemcpyHostToDevice, ctx->stream));
-  if (gap->model == ALN_GAP_DEL_TABLE_INS_TPOS) {
+  if (!b->d_tgi) { int rc = dalloc(ctx, &b->d_tgi, (size_t)std::max<int64_t>(b->t_total, 1)); if (rc) return rc; }
+  if (!b->d_tge) { int rc = dalloc(ctx, &b->d_tge, (size_t)std::max<int64_t>(b->t_total, 1)); if (rc) return rc; }
+  if (gap->model != ALN_GAP_TABLES) {             // per-position coefficient arrays (the table model has none)
+    if (!gap->t_gap_init || !gap->t_gap_extn) return ALN_E_ARG;
+    ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_tgi, gap->t_gap_init, b->t_total * 4, hipMemcpyHostToDevice, ctx->stream));
+    ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_tge, gap->t_gap_extn, b->t_total * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (gap->model == ALN_GAP_DEL_TABLE_INS_TPOS || gap->model == ALN_GAP_TABLES) {
     // Gn2Eval's v_cn and the per-template deletion tables (T x T floats each)
-    if (!gap->t_gap_cn || !gap->del_table || !gap->del_table_off) return ALN_E_ARG;
+    const bool gn2 = gap->model == ALN_GAP_DEL_TABLE_INS_TPOS;
+    if ((gn2 && !gap->t_gap_cn) || !gap->del_table || !gap->del_table_off) return ALN_E_ARG;
     const int ns = (int)b->t_offsets.size() - 1;
     std::vector<int64_t> off(ns);
     int64_t total = 0;
@@ -252,18 +255,32 @@ int upload_tgaps(aln_batch* b, const aln_gap* gap) {
       off[s] = total;
       total += T * T;
     }
-    if (!b->d_tcn) { int rc = dalloc(ctx, &b->d_tcn, (size_t)b->t_total); if (rc) return rc; }
+    if (gn2 && !b->d_tcn) { int rc = dalloc(ctx, &b->d_tcn, (size_t)b->t_total); if (rc) return rc; }
     if (b->d_deltab) { hipFree(b->d_deltab); b->d_deltab = nullptr; }
     if (b->d_deltab_off) { hipFree(b->d_deltab_off); b->d_deltab_off = nullptr; }
     { int rc = dalloc(ctx, &b->d_deltab, (size_t)std::max<int64_t>(total, 1)); if (rc) return rc; }
     ALN_HIP_CHECK(ctx, hipMalloc((void**)&b->d_deltab_off, (size_t)ns * 8));
-    ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_tcn, gap->t_gap_cn, b->t_total * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (gn2) ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_tcn, gap->t_gap_cn, b->t_total * 4, hipMemcpyHostToDevice, ctx->stream));
     for (int s = 0; s < ns; ++s) {      // the caller's tables may sit anywhere: one copy per template into the packed pool
       const int64_t T = b->t_offsets[s + 1] - b->t_offsets[s];
       ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_deltab + off[s], gap->del_table + gap->del_table_off[s], (size_t)(T * T) * 4,
                                         hipMemcpyHostToDevice, ctx->stream));
     }
     ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_deltab_off, off.data(), (size_t)ns * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (!gn2) {
+      // the evaluator's insertion(), three T x Q planes per pair
+      if (!gap->ins_tables || !gap->ins_table_off) return ALN_E_ARG;
+      int64_t itotal = 0;
+      for (int p = 0; p < b->n_pairs; ++p) { b->h_pairs[p].ins_off = itotal; itotal += (int64_t)3 * b->h_pairs[p].Q * b->h_pairs[p].T; }
+      if (b->d_instab) { hipFree(b->d_instab); b->d_instab = nullptr; }
+      { int rc = dalloc(ctx, &b->d_instab, (size_t)std::max<int64_t>(itotal, 1)); if (rc) return rc; }
+      for (int p = 0; p < b->n_pairs; ++p) {
+        const size_t n = (size_t)3 * b->h_pairs[p].Q * b->h_pairs[p].T;
+        ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_instab + b->h_pairs[p].ins_off, gap->ins_tables + gap->ins_table_off[p], n * 4,
+                                          hipMemcpyHostToDevice, ctx->stream));
+      }
+      if (b->n_pairs) ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_pairs, b->h_pairs.data(), sizeof(PairDesc) * b->n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    }
   }
   ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return ALN_OK;
@@ -302,7 +319,7 @@ int aln_batch_dp(aln_batch* b, const aln_sim* sim, const aln_gap* gap, int32_t d
   ALN_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (!valid_align_type(gap->align_type)) return ALN_E_GAPSTYLE;
   if (direction != ALN_FWD && direction != ALN_REV) return ALN_E_ARG;
-  if (gap->model != ALN_GAP_AFFINE_CONST && gap->model != ALN_GAP_AFFINE_TPOS_MIN && gap->model != ALN_GAP_DEL_TABLE_INS_TPOS) return ALN_E_ARG;
+  if (gap->model != ALN_GAP_AFFINE_CONST && gap->model != ALN_GAP_AFFINE_TPOS_MIN && gap->model != ALN_GAP_DEL_TABLE_INS_TPOS && gap->model != ALN_GAP_TABLES) return ALN_E_ARG;
   b->gap = *gap;
   b->sim_kind = sim->kind;
   b->direction = direction;

@@ -21,6 +21,7 @@ struct EvalDev {
   const float* tcn;     // DEL_TABLE_INS_TPOS: Gn2Eval's v_cn; in the kernel-argument prototype these three are POOL bases
   const float* deltab;  // DEL_TABLE_INS_TPOS: this template's T x T deletion table (prototype: base of all tables)
   const int64_t* deltab_off;   // prototype only: first element of template sequence s's table
+  const float* instab;  // TABLES: this pair's three T x Q insertion planes (prototype: base of all pairs' planes)
   // similarity
   int sim_kind;                 // ALN_SIM_SUBMATRIX: codes + table; else plane
   const uint8_t* qc; const uint8_t* tc;
@@ -36,8 +37,8 @@ __device__ __forceinline__ float dev_deletion(const EvalDev& e, int t1, int t2) 
     if (len < 1) return 0.f;
     if (free_end && (t1 == 0 || t2 == e.T - 1)) return 0.f;
     return e.gi + e.ge * (float)(len - 1);
-  } else if (e.model == ALN_GAP_DEL_TABLE_INS_TPOS) {
-    return e.deltab[(size_t)t1 * e.T + t2];     // gn2_eval.h:100-130, materialised by the caller
+  } else if (e.model == ALN_GAP_DEL_TABLE_INS_TPOS || e.model == ALN_GAP_TABLES) {
+    return e.deltab[(size_t)t1 * e.T + t2];     // gn2_eval.h:100-130 / any deletion(t1,t2), materialised by the caller
   } else {
     int dist = t2 - t1;
     if (dist < 2) return 0.f;
@@ -55,6 +56,11 @@ __device__ __forceinline__ float dev_insertion(const EvalDev& e, int q1, int q2,
     if (len < 1) return 0.f;
     if (free_end && (q1 == 0 || q2 == e.Q - 1)) return 0.f;
     return e.gi + e.ge * (float)(len - 1);
+  } else if (e.model == ALN_GAP_TABLES) {               // the evaluator's own insertion(), tabulated: interior / head / tail
+    const size_t QT = (size_t)e.Q * e.T;
+    if (q1 == 0) return e.instab[QT + (size_t)t1 * e.Q + q2];
+    if (q2 == e.Q - 1) return e.instab[2 * QT + (size_t)t1 * e.Q + q1];
+    return e.instab[(size_t)t1 * e.Q + (q2 - q1)];
   } else if (e.model == ALN_GAP_DEL_TABLE_INS_TPOS) {   // gn2_eval.h:132-165: coefficients of t1 only, plus the contact-number term
     int dist = q2 - q1;
     if (dist < 2) return 0.f;
@@ -75,6 +81,7 @@ __device__ __forceinline__ float dev_insertion(const EvalDev& e, int q1, int q2,
 __device__ __forceinline__ void bind_table_model(EvalDev& e, const EvalDev& proto, const PairDesc& pd) {
   e.tcn = proto.tcn ? proto.tcn + pd.t_off : nullptr;
   e.deltab = proto.deltab ? proto.deltab + proto.deltab_off[pd.t_seq] : nullptr;
+  e.instab = proto.instab ? proto.instab + pd.ins_off : nullptr;
 }
 // DPMatrix::getSim — SimilarityMatrix (simmatrix.h:51-72): zero borders, Evaluator::similarity inside
 __device__ __forceinline__ float dev_sim(const EvalDev& e, int i, int j) {

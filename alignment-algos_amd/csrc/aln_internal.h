@@ -24,6 +24,7 @@ struct PairDesc {
   int64_t plane_off;     // first element of this pair's Q x ld planes
   // sub-rectangle of build_subdpm (full build: 0, Q-1, 0, T-1)
   int32_t q0, q1, t0, t1;
+  int64_t ins_off;       // ALN_GAP_TABLES: first element of this pair's three T x Q insertion planes
 };
 
 // Per-pair results kept on the device.
@@ -73,7 +74,8 @@ struct aln_batch {
   int32_t* d_table32;                          // 32x32 int substitution table (fast path)
   float* d_tablef;                             // 32x32 float table (exact path / getSim)
   float* d_tgi; float* d_tge;                  // AFFINE_TPOS_MIN arrays (template pool positions)
-  float* d_tcn = nullptr; float* d_deltab = nullptr; int64_t* d_deltab_off = nullptr;   // DEL_TABLE_INS_TPOS (Gn2Eval)
+  float* d_tcn = nullptr; float* d_deltab = nullptr; int64_t* d_deltab_off = nullptr;   // DEL_TABLE_INS_TPOS (Gn2Eval), TABLES
+  float* d_instab = nullptr;                                                            // TABLES
   int32_t n_tseqs = 0;
   int32_t* d_path;                             // traceback output, n_pairs x path_stride x 2
   int32_t path_stride;

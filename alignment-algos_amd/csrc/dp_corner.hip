@@ -121,7 +121,7 @@ int launch_dp_corner(aln_batch* b) {
   proto.gi = b->gapdev.gi; proto.ge = b->gapdev.ge;
   proto.sim_kind = (b->sim_kind == ALN_SIM_SUBMATRIX) ? ALN_SIM_SUBMATRIX : ALN_SIM_MATRIX;
   proto.tablef = b->d_tablef;
-  proto.tcn = b->d_tcn; proto.deltab = b->d_deltab; proto.deltab_off = b->d_deltab_off;
+  proto.tcn = b->d_tcn; proto.deltab = b->d_deltab; proto.deltab_off = b->d_deltab_off; proto.instab = b->d_instab;
   const bool sub = b->sim_kind == ALN_SIM_SUBMATRIX;
   const bool tpos = b->gapdev.model != ALN_GAP_AFFINE_CONST;
   hipLaunchKernelGGL(dp_corner_kernel, dim3(b->n_pairs), dim3(64), 0, b->ctx->stream, b->d_pairs, proto,

@@ -870,7 +870,7 @@ static size_t blocked_scratch_floats(int ns) { return (size_t)3 * kBR * (ns * 25
 bool dp_exact_blocked_legal(const aln_batch* b) {
   int mx = 0;
   for (const PairDesc& d : b->h_pairs) { const int nT = d.t1 - d.t0; if (nT - 1 > mx) mx = nT - 1; }
-  return mx <= 16 * 256 && b->gapdev.model != ALN_GAP_DEL_TABLE_INS_TPOS;   // the table model runs in the literal kernel
+  return mx <= 16 * 256 && b->gapdev.model != ALN_GAP_DEL_TABLE_INS_TPOS && b->gapdev.model != ALN_GAP_TABLES;   // the table model runs in the literal kernel
 }
 
 int launch_dp_exact_blocked(aln_batch* b) {

@@ -344,7 +344,7 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   proto.gi = b->gapdev.gi; proto.ge = b->gapdev.ge;
   proto.sim_kind = (b->sim_kind == ALN_SIM_SUBMATRIX) ? ALN_SIM_SUBMATRIX : ALN_SIM_MATRIX;
   proto.tablef = b->d_tablef;
-  proto.tcn = b->d_tcn; proto.deltab = b->d_deltab; proto.deltab_off = b->d_deltab_off;
+  proto.tcn = b->d_tcn; proto.deltab = b->d_deltab; proto.deltab_off = b->d_deltab_off; proto.instab = b->d_instab;
   const bool sub = b->sim_kind == ALN_SIM_SUBMATRIX;
   const bool tpos = b->gapdev.model != ALN_GAP_AFFINE_CONST;
   hipLaunchKernelGGL(enumerate_kernel, dim3(1), dim3(64), 0, ctx->stream, b->d_pairs, pair, proto, sub ? b->d_qcodes : nullptr,
@@ -513,7 +513,7 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   proto.gi = b->gapdev.gi; proto.ge = b->gapdev.ge;
   proto.sim_kind = (b->sim_kind == ALN_SIM_SUBMATRIX) ? ALN_SIM_SUBMATRIX : ALN_SIM_MATRIX;
   proto.tablef = b->d_tablef;
-  proto.tcn = b->d_tcn; proto.deltab = b->d_deltab; proto.deltab_off = b->d_deltab_off;
+  proto.tcn = b->d_tcn; proto.deltab = b->d_deltab; proto.deltab_off = b->d_deltab_off; proto.instab = b->d_instab;
   const bool sub = b->sim_kind == ALN_SIM_SUBMATRIX;
   const bool tpos = b->gapdev.model != ALN_GAP_AFFINE_CONST;
   for (auto& ev : evs) BTRY(hipEventCreate(&ev));

@@ -3,6 +3,7 @@
 //   aa <mode> <gi> <ge> <dir> <q> <t> <blosum>   DPMatrix<AASequence,...> fwd/rev + Optimal/Optimal_Rev + ucw, cells via getCell
 //   gn2 <mode> <q.hmap> <t.hmap> <seed>   DPMatrix<HMAPSequence,SMAPSequence,Gn2Eval> with synthetic structural members; prints the
 //                                         tables pre_calculate built (TAB name n v...) so a test can feed them to its checker
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,6 +17,37 @@
 #include "optimal.h"
 #include "optimal_rev.h"
 #include "ucw.h"
+
+// A plugin written against evaluator.h and nothing else (no aln_describe_gaps, no engine types): BLOSUM similarities, a
+// gap cost that is NOT affine (square-root growth), the usual free-end rules.  It must run unchanged.
+template <class S1, class S2>
+class SqrtGapEval : public Evaluator<S1, S2, SqrtGapEval<S1, S2> > {
+ public:
+  SqrtGapEval(const AliParams& p, const SubstitutionMatrix& m) : params(&p), sub(&m) {}
+  float similarity(const S1& q, const S2& t, int qi, int ti) const {
+    if (q[qi]->isHead() || q[qi]->isTail() || t[ti]->isHead() || t[ti]->isTail()) return 0.f;
+    return sub->score(q[qi]->olc, t[ti]->olc);
+  }
+  float deletion(const S1&, const S2& t, int, int, int t1, int t2) const {
+    int len = t2 - t1 - 1;
+    if (len < 1) return 0.f;
+    if (free_del() && (t[t1]->isHead() || t[t2]->isTail())) return 0.f;
+    return params->gap_init_penalty + params->gap_extn_penalty * std::sqrt((float)len);
+  }
+  float insertion(const S1& q, const S2&, int q1, int q2, int, int) const {
+    int len = q2 - q1 - 1;
+    if (len < 1) return 0.f;
+    if (free_ins() && (q[q1]->isHead() || q[q2]->isTail())) return 0.f;
+    return params->gap_init_penalty + params->gap_extn_penalty * std::sqrt((float)len);
+  }
+  void pre_calculate(const S1&, const S2&) const {}
+  void post_process(SimilarityMatrix&) const {}
+ private:
+  bool free_del() const { return params->align_type == local || params->align_type == semi_local || params->align_type == local_global; }
+  bool free_ins() const { return params->align_type == local || params->align_type == semi_local || params->align_type == global_local; }
+  const AliParams* params;
+  const SubstitutionMatrix* sub;
+};
 
 static unsigned fbits(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 
@@ -90,6 +122,32 @@ int main(int argc, char** argv) {
         printf("\n");
       };
       tri("dist", t.distance); tri("vv_gi", ev.vv_gi); tri("vv_ge", ev.vv_ge); tri("vv_cd", ev.vv_cd);
+      return 0;
+    }
+    if (cmd == "plain") {       // plain <mode> <gi> <ge> <q> <t> <blosum>: the unmodified plugin above; prints H/PQ/PT, S and its gap tables
+      AliParams p;
+      p.align_type = (align_t)atoi(argv[2]);
+      p.gap_init_penalty = (float)atof(argv[3]);
+      p.gap_extn_penalty = (float)atof(argv[4]);
+      AASequence q, t;
+      q.seq_name = "query"; t.seq_name = "templ";
+      q.append("^"); q.append(argv[5]); q.append("$");
+      t.append("^"); t.append(argv[6]); t.append("$");
+      BlosumMatrix blosum(argv[7]);
+      typedef SqrtGapEval<AASequence, AASequence> PEval;
+      PEval ev(p, blosum);
+      DPMatrix<AASequence, AASequence, PEval> dpm(q, t, ev, fwd, p.align_type);
+      Optimal<AASequence, AASequence, PEval> opt(p.align_type);
+      AlignmentSet<AASequence, AASequence, PEval> as(dpm, opt);
+      dump("OPT", as);
+      const int Q = dpm.getQuerySize(), T = dpm.getTemplateSize();
+      printf("DIM %d %d\nH", Q, T);
+      for (int i = 0; i < Q; ++i) for (int j = 0; j < T; ++j) printf(" %08x", fbits(dpm.getCell(i, j)->score));
+      printf("\nPQ");
+      for (int i = 0; i < Q; ++i) for (int j = 0; j < T; ++j) printf(" %d", dpm.getCell(i, j)->prev_query_idx);
+      printf("\nPT");
+      for (int i = 0; i < Q; ++i) for (int j = 0; j < T; ++j) printf(" %d", dpm.getCell(i, j)->prev_template_idx);
+      printf("\n");
       return 0;
     }
     AliParams p;

@@ -35,8 +35,11 @@ enum aln_direction_t { ALN_FWD = 1, ALN_REV = 2 };   /* dpmatrix.h:23-26 */
 enum aln_gap_model {
   ALN_GAP_AFFINE_CONST = 0,     /* AASubstitutionEval::deletion/insertion, aasubalib.h:27-77 */
   ALN_GAP_AFFINE_TPOS_MIN = 1,  /* Hmap2Eval / HMAPaliEval, hmap2_eval.h:41-95 (min of the two template positions) */
-  ALN_GAP_DEL_TABLE_INS_TPOS = 2 /* Gn2Eval, gn2_eval.h:100-165: deletion(t1,t2) is a per-template table (vv_gi/vv_ge/vv_cd + the
+  ALN_GAP_DEL_TABLE_INS_TPOS = 2, /* Gn2Eval, gn2_eval.h:100-165: deletion(t1,t2) is a per-template table (vv_gi/vv_ge/vv_cd + the
                                    8100 distance rule, materialised by the caller), insertion = (gi[t1] + ge[t1]*(di-2)) + cn[t1] */
+  ALN_GAP_TABLES = 3            /* any Evaluator whose deletion() depends on (t1,t2) and whose insertion() depends on (t1, q2-q1)
+                                   away from the query ends: both functions materialised by the caller (aln_lowering.h does it
+                                   for an arbitrary evaluator.h plugin; covers GnoaliEval, gnoalib.h:90-185) */
 };
 
 enum aln_sim_kind {
@@ -112,8 +115,13 @@ typedef struct {
    * pool (gn2_eval.cpp:113-130).  del_table: template sequence s (T residues) owns T*T floats at del_table[del_table_off[s]],
    * entry [t1*T + t2] = exactly what Evaluator::deletion(q,t,.,.,t1,t2) returns for t1 < t2 (end rules included). */
   const float* t_gap_cn;
-  const float* del_table;
+  const float* del_table;       /* DEL_TABLE_INS_TPOS and TABLES */
   const int64_t* del_table_off; /* n template sequences */
+  /* TABLES only: pair p (Q x T) owns three T x Q planes at ins_tables[ins_table_off[p]]: [0][t1*Q + d] = insertion(q1,q1+d,t1,t1+1)
+   * for interior q1 and q1+d; [1][t1*Q + q2] = insertion(0,q2,t1,t1+1); [2][t1*Q + q1] = insertion(q1,Q-1,t1,t1+1).  No
+   * end-gap rule is applied by the library in this model: the tables are the evaluator's own values. */
+  const float* ins_tables;
+  const int64_t* ins_table_off; /* n pairs */
 } aln_gap;
 
 /* Similarity source. */

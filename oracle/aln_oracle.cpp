@@ -35,7 +35,8 @@ extern "C" {
 
 // aasubalib.h:27-51 / hmap2_eval.h:41-67
 float orc_deletion(const orc_gap* g, int Q, int T, int q1, int q2, int t1, int t2, int* err) {
-  (void)Q; (void)q1; (void)q2;
+  (void)Q;
+  if (g->model == ORC_GAP_CALLBACK) return g->del_cb(q1, q2, t1, t2);
   if (g->model == ORC_GAP_GN2) {                   // gn2_eval.h:100-130
     int di = t2 - t1;
     if (di < 2) return 0;
@@ -82,6 +83,7 @@ float orc_deletion(const orc_gap* g, int Q, int T, int q1, int q2, int t1, int t
 // aasubalib.h:53-77 / hmap2_eval.h:69-95 (coefficients come from the TEMPLATE positions t1,t2)
 float orc_insertion(const orc_gap* g, int Q, int T, int q1, int q2, int t1, int t2, int* err) {
   (void)T;
+  if (g->model == ORC_GAP_CALLBACK) return g->ins_cb(q1, q2, t1, t2);
   if (g->model == ORC_GAP_GN2) {                   // gn2_eval.h:132-165
     int di = q2 - q1;
     if (di < 2) return 0;

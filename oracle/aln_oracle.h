@@ -33,6 +33,7 @@ enum { ORC_FWD = 1, ORC_REV = 2 };
 /* gap models */
 enum { ORC_GAP_AFFINE_CONST = 0,    /* AASubstitutionEval, aasubalib.h:27-77 */
        ORC_GAP_AFFINE_TPOS_MIN = 1, /* Hmap2Eval / HMAPaliEval, hmap2_eval.h:41-95 */
+       ORC_GAP_CALLBACK = 3,        /* any deletion(q1,q2,t1,t2) / insertion(q1,q2,t1,t2) supplied by the test (arbitrary plugins) */
        ORC_GAP_GN2 = 2              /* Gn2Eval, gn2_eval.h:100-165 — parity UNPINNED (its inputs come from the absent Troll library) */ };
 
 typedef struct {
@@ -47,6 +48,9 @@ typedef struct {
   const float* vvgi;
   const float* vvge;
   const float* vvcd;
+  /* model 3: the test's own gap functions */
+  float (*del_cb)(int q1, int q2, int t1, int t2);
+  float (*ins_cb)(int q1, int q2, int t1, int t2);
 } orc_gap;
 
 /* error codes mirror the reference's throw sites */

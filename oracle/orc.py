@@ -13,14 +13,15 @@ _LIB = None
 
 GLOBAL_LOCAL, GLOBAL, LOCAL_GLOBAL, LOCAL, SEMI_LOCAL = 0, 1, 2, 3, 4
 FWD, REV = 1, 2
-GAP_AFFINE_CONST, GAP_AFFINE_TPOS_MIN, GAP_GN2 = 0, 1, 2
+GAP_AFFINE_CONST, GAP_AFFINE_TPOS_MIN, GAP_GN2, GAP_CALLBACK = 0, 1, 2, 3
+GAPFN = C.CFUNCTYPE(C.c_float, C.c_int, C.c_int, C.c_int, C.c_int)
 
 
 class OrcGap(C.Structure):
     _fields_ = [("model", C.c_int), ("align_type", C.c_int), ("gi", C.c_float), ("ge", C.c_float),
                 ("tgi", C.POINTER(C.c_float)), ("tge", C.POINTER(C.c_float)), ("tcn", C.POINTER(C.c_float)),
                 ("dist", C.POINTER(C.c_float)), ("vvgi", C.POINTER(C.c_float)), ("vvge", C.POINTER(C.c_float)),
-                ("vvcd", C.POINTER(C.c_float))]
+                ("vvcd", C.POINTER(C.c_float)), ("del_cb", GAPFN), ("ins_cb", GAPFN)]
 
 
 def build():
@@ -62,10 +63,15 @@ def f32(x):
 class Gap:
     """Gap model descriptor; keeps numpy arrays alive."""
 
-    def __init__(self, align_type, gi=0.0, ge=0.0, tgi=None, tge=None, gn2=None):
+    def __init__(self, align_type, gi=0.0, ge=0.0, tgi=None, tge=None, gn2=None, callbacks=None):
         self.g = OrcGap()
         self.g.align_type = int(align_type)
-        if gn2 is not None:
+        if callbacks is not None:
+            # (deletion(q1,q2,t1,t2), insertion(q1,q2,t1,t2)) python callables returning float: an arbitrary plugin's gap functions
+            self.g.model = GAP_CALLBACK
+            self.cbs = (GAPFN(callbacks[0]), GAPFN(callbacks[1]))
+            self.g.del_cb, self.g.ins_cb = self.cbs
+        elif gn2 is not None:
             # Gn2Eval tables: dict v_gi, v_ge, v_cn [T]; dist, vv_gi, vv_ge, vv_cd [T,T] indexed [p2, p1]
             self.g.model = GAP_GN2
             self.keep = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in gn2.items()}

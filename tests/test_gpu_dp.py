@@ -1,6 +1,8 @@
 """-m gpu parity tests of the DP build + Optimal traceback, through the C ABI, against
 (a) the golden vectors produced by the real reference and (b) the oracle on seeded inputs.
 Bit-exact: scores compared as uint32 bit patterns, pointers and pair lists as integers."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -490,3 +492,67 @@ def test_edge_sizes(blosum62):
     assert "dp_affine_int" in res[0][0], res[0][0]
     for a, c in zip(res[0][1], res[1][1]):
         assert np.array_equal(np.asarray(a).view(np.uint32), np.asarray(c).view(np.uint32))
+
+
+def tabulate_gaps(gap, Q, T):
+    """What aln_lowering.h does for an arbitrary evaluator, here with the oracle's gap functions as "the evaluator":
+    deletion(t1,t2) for every t1 < t2, insertion for interior / head / tail query positions."""
+    L = orc.lib()
+    err = C.c_int(0)
+    D = np.zeros((T, T), dtype=np.float32)
+    for t1 in range(T):
+        for t2 in range(t1 + 1, T):
+            D[t1, t2] = L.orc_deletion(gap.ref, Q, T, 1, 2, t1, t2, C.byref(err))
+    I = np.zeros((3, T, Q), dtype=np.float32)
+    for t1 in range(T - 1):
+        for d in range(1, Q - 2):
+            I[0, t1, d] = L.orc_insertion(gap.ref, Q, T, 1, 1 + d, t1, t1 + 1, C.byref(err))
+        for q2 in range(1, Q):
+            I[1, t1, q2] = L.orc_insertion(gap.ref, Q, T, 0, q2, t1, t1 + 1, C.byref(err))
+        for q1 in range(0, Q - 1):
+            I[2, t1, q1] = L.orc_insertion(gap.ref, Q, T, q1, Q - 1, t1, t1 + 1, C.byref(err))
+    assert err.value == 0
+    return D, I
+
+
+@pytest.mark.parametrize("direction", ["fwd", "rev"])
+def test_tabulated_gap_model(direction):
+    """ALN_GAP_TABLES: the evaluator's deletion()/insertion() fully materialised (what the host mirror does for a plugin that
+    does not name a closed-form model).  Tables filled from the oracle's min(t[t1],t[t2]) functions must reproduce the
+    oracle's DP for that model bit for bit, in every end-gap style, plus Optimal and a constrained enumeration."""
+    rng = np.random.RandomState(21)
+    dims = [(7, 11), (30, 41), (50, 36)]
+    planes, tgis, tges = [], [], []
+    for (Q, T) in dims:
+        S = rng.normal(0.0, 1.3, size=(Q, T)).astype(np.float32)
+        S[0, :] = 0; S[-1, :] = 0; S[:, 0] = 0; S[:, -1] = 0
+        planes.append(S)
+        tgis.append(rng.uniform(2.0, 6.0, size=T).astype(np.float32))
+        tges.append(rng.uniform(0.1, 0.6, size=T).astype(np.float32))
+    for mode in range(5):
+        gaps = [orc.Gap(mode, tgi=tgis[p], tge=tges[p]) for p in range(len(dims))]
+        tabs = [tabulate_gaps(gaps[p], *dims[p]) for p in range(len(dims))]
+        b = aln_amd.Batch(gpu_util.ctx(), ["A" * (Q - 2) for Q, T in dims], ["A" * (T - 2) for Q, T in dims])
+        b.dp_simmatrix(planes, mode, 0, 0, DIRS[direction], del_tables=[t[0] for t in tabs], ins_tables=[t[1] for t in tabs])
+        assert "dp_exact_kernel" in b.kernel_name()
+        scores, lists, status = b.optimal()
+        for p, S in enumerate(planes):
+            rc, D0, PQ0, PT0 = orc.dp_build(S, gaps[p], orc.FWD if direction == "fwd" else orc.REV)
+            D, PQ, PT = b.get_cells(p)
+            assert np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (p, mode, direction)
+            assert np.array_equal(PQ, PQ0) and np.array_equal(PT, PT0), (p, mode, direction)
+            rc2, sc, pairs = orc.optimal(D0, PQ0, PT0, mode == 3, kind=direction)
+            assert np.float32(scores[p]).view(np.uint32) == sc.view(np.uint32) and np.array_equal(lists[p], pairs)
+            if direction == "fwd" and mode in (1, 3):
+                T = dims[p][1]
+                flags = orc.make_subopt_regions(T, 4)
+                s = orc.AliSet()
+                s.push(pairs, sc)
+                orc.enumerate_noa("cw", D0, PQ0, PT0, S, gaps[p], flags, 10, 0.1, s)
+                got = b.enumerate(p, "cw", 10, 0.1, flags, max_alignments=max(10, len(s)) + 2)
+                assert len(got) == len(s)
+                for k, g in enumerate(got):
+                    r = s.get(k)
+                    assert np.float32(g["score"]).view(np.uint32) == r["score"].view(np.uint32), (p, mode, k)
+                    assert np.array_equal(g["pairs"], r["pairs"])
+        b.close()

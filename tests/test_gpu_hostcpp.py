@@ -63,6 +63,39 @@ def test_hmap2eval_through_host_classes(mode, tmp_path):
     assert a["score"].view(np.uint32) == sc.view(np.uint32) and np.array_equal(a["pairs"], pairs)
 
 
+@pytest.mark.parametrize("mode", [1, 3, 4, 0])
+def test_unmodified_plugin_evaluator(mode, blosum62):
+    """A plugin written against evaluator.h only (host_api_test.cpp SqrtGapEval: BLOSUM similarities, square-root gap growth,
+    free end gaps per align_t; no aln_describe_gaps) runs unchanged: aln_lowering.h tabulates its deletion()/insertion()
+    (ALN_GAP_TABLES).  The oracle evaluates the same gap functions through callbacks, candidate by candidate."""
+    alpha, table = blosum62
+    q, t = homolog_pair(96000 + mode, 37, sub_rate=0.25, indel=3)
+    gi, ge = np.float32(7.5), np.float32(1.25)
+    got = run(["plain", mode, float(gi), float(ge), q, t, BLOSUM])
+    Q, T = len(q) + 2, len(t) + 2
+    free_del, free_ins = mode in (3, 4, 2), mode in (3, 4, 0)
+
+    def dele(q1, q2, t1, t2):
+        ln = t2 - t1 - 1
+        if ln < 1 or (free_del and (t1 == 0 or t2 == T - 1)):
+            return 0.0
+        return float(np.float32(gi + np.float32(ge * np.sqrt(np.float32(ln)))))
+
+    def ins(q1, q2, t1, t2):
+        ln = q2 - q1 - 1
+        if ln < 1 or (free_ins and (q1 == 0 or q2 == Q - 1)):
+            return 0.0
+        return float(np.float32(gi + np.float32(ge * np.sqrt(np.float32(ln)))))
+
+    S = orc.sim_submatrix(q, t, alpha, table)
+    rc, D, PQ, PT = orc.dp_build(S, orc.Gap(mode, callbacks=(dele, ins)), islocal=(mode == 3))
+    assert np.array_equal(got["H"].view(np.uint32), D.view(np.uint32))
+    assert np.array_equal(got["PQ"], PQ) and np.array_equal(got["PT"], PT)
+    rc2, sc, pairs = orc.optimal(D, PQ, PT, mode == 3)
+    a = got["sets"]["OPT"]["alis"][0]
+    assert a["score"].view(np.uint32) == sc.view(np.uint32) and np.array_equal(a["pairs"], pairs)
+
+
 @pytest.mark.parametrize("mode", [1, 4, 3])
 def test_gn2eval_through_host_classes(mode, tmp_path):
     """Gn2Eval (hostcpp/gn2_eval.h) lowered to a host similarity plane + ALN_GAP_DEL_TABLE_INS_TPOS: the program prints the
