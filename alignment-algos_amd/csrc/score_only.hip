@@ -10,6 +10,7 @@
 // bound by VALU issue (about 6 half-rate + 8 full-rate instructions per cell), not by HBM.
 // Grid: x = template index, y = query index inside the caller's row block; templates are replicated on every GPU,
 // query rows are what ranks shard.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -41,6 +42,7 @@ struct ScoreArgs {
   const uint8_t* tcodes; const int64_t* toff;   // template pool
   const int32_t* table32;                       // 32 x 32
   const int32_t* tsel;                          // blockIdx.x -> template index (templates are launched by length class)
+  const int32_t* qsel;                          // packed kernel: query rows of the slab sorted by length (neighbours share a wave)
   float* scores;                                // rows x n_t
   int q_begin, n_t;
   int gi, ge;
@@ -165,6 +167,167 @@ __global__ __launch_bounds__(64) void score_local_kernel(ScoreArgs a) {
   if (lane == 0) a.scores[(size_t)blockIdx.y * a.n_t + ti] = (float)m;
 }
 
+
+// ---- two queries per wave in packed 16-bit lanes --------------------------------------------------------------------
+// v_max_i32 issues at half rate on gfx950 and so does v_pk_max_i16 — which does two.  When every intermediate fits in 15 bits
+// (checked on the host) the low half of each register carries query A and the high half query B against the same template:
+// the recurrence, the DPP prefix scans and the one-column shift act on both halves at once, the substitution score comes
+// from a per-row table of packed pairs (tab[qA[i]][c], tab[qB[i]][c]) that 32 lanes rebuild in LDS for every row.
+typedef short s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s2 as_s2(int v) { return __builtin_bit_cast(s2, v); }
+__device__ __forceinline__ int as_i(s2 v) { return __builtin_bit_cast(int, v); }
+__device__ __forceinline__ s2 dup2(int v) { return as_s2((v & 0xFFFF) | (v << 16)); }
+__device__ __forceinline__ s2 pmax(s2 a, s2 b) { return __builtin_elementwise_max(a, b); }
+constexpr int kNeg16 = -12000;          // "minus infinity" of the packed kernel: below every real value, clear of int16 wrap-around
+
+__device__ __forceinline__ s2 wave_incl_max_pk(s2 v) {
+  const int ident = (int)0x80008000;
+  v = pmax(v, as_s2(sdpp<0x111>(ident, as_i(v))));
+  v = pmax(v, as_s2(sdpp<0x112>(ident, as_i(v))));
+  v = pmax(v, as_s2(sdpp<0x114>(ident, as_i(v))));
+  v = pmax(v, as_s2(sdpp<0x118>(ident, as_i(v))));
+  v = pmax(v, as_s2(sdpp<0x142, 0xA>(ident, as_i(v))));
+  v = pmax(v, as_s2(sdpp<0x143, 0xC>(ident, as_i(v))));
+  return v;
+}
+
+template <int R>
+__global__ __launch_bounds__(64) void score_local_pk_kernel(ScoreArgs a, int n_rows) {
+  __shared__ int tab[32 * 32];
+  __shared__ int prow[2][32];           // packed substitution row of the current query residues, double-buffered by row parity
+  const int lane = threadIdx.x;
+  for (int k = lane; k < 32 * 32; k += 64) tab[k] = a.table32[k];
+  __syncthreads();
+  const int ti = a.tsel[blockIdx.x];
+  const int rowA = a.qsel[2 * blockIdx.y], rowB_ = a.qsel[(2 * blockIdx.y + 1 < n_rows) ? 2 * blockIdx.y + 1 : 2 * blockIdx.y];
+  const int qiA = a.q_begin + rowA, qiB = a.q_begin + rowB_;
+  const uint8_t* __restrict__ qcA = a.qcodes + a.qoff[qiA];
+  const uint8_t* __restrict__ qcB = a.qcodes + a.qoff[qiB];
+  const uint8_t* __restrict__ tc = a.tcodes + a.toff[ti];
+  const int QA = (int)(a.qoff[qiA + 1] - a.qoff[qiA]), QB = (int)(a.qoff[qiB + 1] - a.qoff[qiB]);
+  const int T = (int)(a.toff[ti + 1] - a.toff[ti]);
+  const int Qm = QA > QB ? QA : QB, Qs = QA > QB ? QB : QA;
+  const int gi = a.gi, ge = a.ge;
+  const int cb = 4 * lane;
+  const int gime = gi - ge;
+  const s2 zero2 = dup2(0), neg2 = dup2(kNeg16);
+
+  int code4[R][4], inm[R][4];
+  s2 gec[R][4], ekc[R][4];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const int c = cb + 256 * r + x;
+      int code = kCodeTail;
+      if (c < T) code = tc[c];
+      code4[r][x] = code * 4;
+      gec[r][x] = dup2(ge * c);
+      ekc[r][x] = dup2(ge * c + gime);
+      inm[r][x] = ((unsigned)(c - 1) < (unsigned)(T - 2)) ? -1 : 0;
+    }
+  s2 d[R][4], gmx[R][4], cv[R], ak[R][4];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    cv[r] = neg2;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { d[r][x] = zero2; gmx[r][x] = neg2; ak[r][x] = neg2; }
+  }
+  s2 lmax = zero2, snap = zero2;
+  // the packed substitution row of query row i: lanes 0..31 build it (residue indices clamped for the shorter query)
+  auto build_row = [&](int i) {
+    if (lane < 32) {
+      const int ia = i < QA ? i : QA - 1, ib = i < QB ? i : QB - 1;
+      const int va = tab[(int)qcA[ia] * 32 + lane], vb = tab[(int)qcB[ib] * 32 + lane];
+      prow[i & 1][lane] = (va & 0xFFFF) | (vb << 16);
+    }
+    __syncthreads();
+  };
+  auto row_at = [&](int i, int c4) -> s2 {
+    return as_s2(*reinterpret_cast<const int*>(reinterpret_cast<const char*>(prow[i & 1]) + c4));
+  };
+  auto finish_row = [&]() {
+    s2 sk = neg2;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      s2 tk = neg2;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        s2 A = d[r][x] + gec[r][x];
+        if (r == 0 && x == 0) A = (lane == 0) ? neg2 : A;    // column 0 is never a source
+        ak[r][x] = A;
+        tk = pmax(tk, A);
+      }
+      lmax = pmax(pmax(lmax, pmax(d[r][0], d[r][1])), pmax(d[r][2], d[r][3]));
+      const s2 ik = wave_incl_max_pk(tk);
+      const s2 ek = as_s2(sdpp<0x138>(as_i(neg2), as_i(ik)));
+      cv[r] = pmax(sk, ek);
+      sk = pmax(sk, as_s2(__builtin_amdgcn_readlane(as_i(ik), 63)));
+    }
+  };
+  if (Qs < 3) snap = zero2;                                  // a query without interior rows scores 0
+  if (Qm >= 3) {
+    build_row(1);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const s2 h = pmax(row_at(1, code4[r][x]), zero2);
+        d[r][x] = as_s2(as_i(h) & inm[r][x]);
+      }
+    finish_row();
+    if (Qs - 2 == 1) snap = lmax;
+  }
+  for (int i = 2; i <= Qm - 2; ++i) {
+    build_row(i);
+    const s2 roff = dup2(gi + ge * (i - 2));
+    const s2 rowB = dup2(ge * (i - 1));
+    s2 bk[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      s2 pv = cv[r];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const s2 m = d[r][x];
+        const s2 e = pv - ekc[r][x];
+        const s2 f = gmx[r][x] - roff;
+        bk[r][x] = pmax(pmax(m, e), f);
+        pv = pmax(pv, ak[r][x]);
+        gmx[r][x] = pmax(gmx[r][x], m + rowB);
+      }
+    }
+    int prev_k = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int uk = sdpp<0x138>(0, as_i(bk[r][3]));
+      if (r > 0) uk = (lane == 0) ? prev_k : uk;
+      prev_k = __builtin_amdgcn_readlane(as_i(bk[r][3]), 63);
+      const bool masked = (r == 0) || (256 * (r + 1) > T - 1);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int c = cb + 256 * r + x;
+        const s2 sv = row_at(i, code4[r][x]);
+        s2 h = pmax(((x == 0) ? as_s2(uk) : bk[r][x - 1]) + sv, zero2);
+        if (r == 0 && x == 1) h = (c == 1) ? pmax(sv, zero2) : h;
+        if (masked) h = as_s2(as_i(h) & inm[r][x]);
+        d[r][x] = h;
+      }
+    }
+    finish_row();
+    if (i == Qs - 2) snap = lmax;                            // the shorter query ends here; later rows of its half are not its own
+  }
+  // the longer query's half of lmax, the shorter one's half of snap
+  const int full = as_i(lmax), part = as_i(snap);
+  int mA = (short)(((QA >= QB) ? full : part) & 0xFFFF);
+  int mB = (short)((((QB >= QA) ? full : part) >> 16) & 0xFFFF);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { mA = max(mA, __shfl_xor(mA, o)); mB = max(mB, __shfl_xor(mB, o)); }
+  if (lane == 0) {
+    a.scores[(size_t)rowA * a.n_t + ti] = (float)mA;
+    if (rowB_ != rowA) a.scores[(size_t)rowB_ * a.n_t + ti] = (float)mB;
+  }
+}
+
 }  // namespace aln
 
 using namespace aln;
@@ -220,8 +383,8 @@ extern "C" int aln_score_all_vs_all(aln_ctx* ctx, const aln_seqs* queries, const
   if (rows == 0 || n_t == 0) return ALN_OK;
 
   ScoreArgs a = {};
-  uint8_t *dq = nullptr, *dt = nullptr; int64_t *dqo = nullptr, *dto = nullptr; int32_t* dtab = nullptr; float* dsc = nullptr; int32_t* dsel = nullptr;
-  auto cleanup = [&]() { hipFree(dq); hipFree(dt); hipFree(dqo); hipFree(dto); hipFree(dtab); hipFree(dsc); hipFree(dsel); };
+  uint8_t *dq = nullptr, *dt = nullptr; int64_t *dqo = nullptr, *dto = nullptr; int32_t* dtab = nullptr; float* dsc = nullptr; int32_t* dsel = nullptr; int32_t* dqsel = nullptr;
+  auto cleanup = [&]() { hipFree(dq); hipFree(dt); hipFree(dqo); hipFree(dto); hipFree(dtab); hipFree(dsc); hipFree(dsel); hipFree(dqsel); };
 #define STRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup(); return ALN_E_HIP; } } while (0)
   STRY(hipMalloc((void**)&dq, qc.size())); STRY(hipMalloc((void**)&dt, tc.size()));
   STRY(hipMalloc((void**)&dqo, (size_t)(queries->n_seqs + 1) * 8)); STRY(hipMalloc((void**)&dto, (size_t)(n_t + 1) * 8));
@@ -247,10 +410,24 @@ extern "C" int aln_score_all_vs_all(aln_ctx* ctx, const aln_seqs* queries, const
   }
   STRY(hipMalloc((void**)&dsel, (size_t)n_t * 4));
   STRY(hipMemcpyAsync(dsel, order.data(), (size_t)n_t * 4, hipMemcpyHostToDevice, ctx->stream));
+  // packed 16-bit lanes (two queries per wave) when every intermediate provably fits: best local score <= maxs * min(Q,T),
+  // A keys add ge * column, the "minus infinity" -12000 must stay below every real candidate and clear of wrap-around
+  const double L = (double)std::max(maxQ, maxT), best = maxs * (double)std::min(maxQ, maxT);
+  const bool packed = best + ge * L + maxs < 30000.0 && ge * L + gi + maxs < 8000.0 && maxs < 2048.0 && !getenv("ALN_SCORE_NO_PACKED");
   const dim3 block(64);
   // blockIdx.y is limited to 65535: walk the query rows in slabs
   for (int r0 = 0; r0 < rows; r0 += 32768) {
     const int nr = std::min(32768, rows - r0);
+    if (packed) {       // pair queries of similar length: a wave runs to the longer one's last row
+      std::vector<int32_t> qo(nr);
+      for (int k = 0; k < nr; ++k) qo[k] = k;
+      std::stable_sort(qo.begin(), qo.end(), [&](int32_t x, int32_t y) {
+        return queries->offsets[q_begin + r0 + x + 1] - queries->offsets[q_begin + r0 + x] <
+               queries->offsets[q_begin + r0 + y + 1] - queries->offsets[q_begin + r0 + y];
+      });
+      if (!dqsel) STRY(hipMalloc((void**)&dqsel, (size_t)std::min(rows, 32768) * 4));
+      STRY(hipMemcpy(dqsel, qo.data(), (size_t)nr * 4, hipMemcpyHostToDevice));   // synchronous: qo dies at the end of this scope
+    }
     for (int r = 1; r <= 8; ++r) {
       const int nc = cls_begin[r + 1] - cls_begin[r];
       if (nc == 0) continue;
@@ -258,6 +435,20 @@ extern "C" int aln_score_all_vs_all(aln_ctx* ctx, const aln_seqs* queries, const
       s.q_begin = q_begin + r0;
       s.scores = dsc + (size_t)r0 * n_t;
       s.tsel = dsel + cls_begin[r];
+      s.qsel = dqsel;
+      if (packed) {
+        const dim3 grid(nc, (nr + 1) / 2);             // two query rows per wave
+        switch (r) {
+          case 1: hipLaunchKernelGGL(score_local_pk_kernel<1>, grid, block, 0, ctx->stream, s, nr); break;
+          case 2: hipLaunchKernelGGL(score_local_pk_kernel<2>, grid, block, 0, ctx->stream, s, nr); break;
+          case 3: hipLaunchKernelGGL(score_local_pk_kernel<3>, grid, block, 0, ctx->stream, s, nr); break;
+          case 4: hipLaunchKernelGGL(score_local_pk_kernel<4>, grid, block, 0, ctx->stream, s, nr); break;
+          case 5: hipLaunchKernelGGL(score_local_pk_kernel<5>, grid, block, 0, ctx->stream, s, nr); break;
+          case 6: hipLaunchKernelGGL(score_local_pk_kernel<6>, grid, block, 0, ctx->stream, s, nr); break;
+          case 7: hipLaunchKernelGGL(score_local_pk_kernel<7>, grid, block, 0, ctx->stream, s, nr); break;
+          default: hipLaunchKernelGGL(score_local_pk_kernel<8>, grid, block, 0, ctx->stream, s, nr); break;
+        }
+      } else {
       const dim3 grid(nc, nr);
       switch (r) {
         case 1: hipLaunchKernelGGL(score_local_kernel<1>, grid, block, 0, ctx->stream, s); break;
@@ -268,6 +459,7 @@ extern "C" int aln_score_all_vs_all(aln_ctx* ctx, const aln_seqs* queries, const
         case 6: hipLaunchKernelGGL(score_local_kernel<6>, grid, block, 0, ctx->stream, s); break;
         case 7: hipLaunchKernelGGL(score_local_kernel<7>, grid, block, 0, ctx->stream, s); break;
         default: hipLaunchKernelGGL(score_local_kernel<8>, grid, block, 0, ctx->stream, s); break;
+      }
       }
       STRY(hipGetLastError());
     }

@@ -48,6 +48,13 @@ def test_scores_equal_plane_path_and_oracle(tmax, blosum62):
     # row blocks (what one rank of a sharded job computes)
     blk = aln_amd.score_all_vs_all(ctx, qs, ts, alpha, table, 11, 1, 2, 7)
     assert np.array_equal(blk, got[2:7])
+    # the default is the packed two-queries-per-wave kernel; the one-query 32-bit kernel must agree
+    import os
+    os.environ["ALN_SCORE_NO_PACKED"] = "1"
+    try:
+        assert np.array_equal(aln_amd.score_all_vs_all(ctx, qs, ts, alpha, table, 11, 1), got)
+    finally:
+        del os.environ["ALN_SCORE_NO_PACKED"]
 
 
 def test_score_only_rejects_what_it_cannot_do(blosum62):
