@@ -312,7 +312,8 @@ int run_dp(aln_batch* b, bool simplane_integral) {
 
 extern "C" {
 
-int aln_batch_dp(aln_batch* b, const aln_sim* sim, const aln_gap* gap, int32_t direction, int32_t algo, int32_t bug_b4) {
+// everything of aln_batch_dp except the launch: parameters, uploads, similarity planes
+static int prepare_dp(aln_batch* b, const aln_sim* sim, const aln_gap* gap, int32_t direction, int32_t algo, int32_t bug_b4, bool* integral_out) {
   if (!b || !sim || !gap) return ALN_E_ARG;
   if (b->score_only) return ALN_E_ARG;
   aln_ctx* ctx = b->ctx;
@@ -347,7 +348,15 @@ int aln_batch_dp(aln_batch* b, const aln_sim* sim, const aln_gap* gap, int32_t d
   }
   else return ALN_E_ARG;
   b->gap.t_gap_init = nullptr; b->gap.t_gap_extn = nullptr;        // host pointers are not retained
-  ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_pairs, b->h_pairs.data(), sizeof(PairDesc) * b->n_pairs, hipMemcpyHostToDevice, ctx->stream));
+  if (b->n_pairs) ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_pairs, b->h_pairs.data(), sizeof(PairDesc) * b->n_pairs, hipMemcpyHostToDevice, ctx->stream));
+  *integral_out = integral;
+  return ALN_OK;
+}
+
+int aln_batch_dp(aln_batch* b, const aln_sim* sim, const aln_gap* gap, int32_t direction, int32_t algo, int32_t bug_b4) {
+  bool integral = false;
+  int rc = prepare_dp(b, sim, gap, direction, algo, bug_b4, &integral);
+  if (rc) return rc;
   return run_dp(b, integral);
 }
 
@@ -366,8 +375,10 @@ int aln_batch_dp_sub(aln_batch* b, const aln_sim* sim, const aln_gap* gap, int32
     if (q0 < 0 || t0 < 0 || q1 >= d.Q || t1 >= d.T) return ALN_E_ARG;
     if (q1 <= q0 || t1 <= t0) return ALN_E_BOUNDS;
   }
-  // same parameter handling as a full build, then narrow every pair to its rectangle and use the exact kernel
-  int rc = aln_batch_dp(b, sim, gap, direction, ALN_DP_EXACT, 0);
+  // same parameter handling as a full build (without launching one), then narrow every pair to its rectangle and use the
+  // exact kernel: a batch of small rectangles is one launch (the reference's SSSS loop fill builds them one by one, ssss.h:621-631)
+  bool integral = false;
+  int rc = prepare_dp(b, sim, gap, direction, ALN_DP_EXACT, 0, &integral);
   if (rc) return rc;
   for (int p = 0; p < b->n_pairs; ++p) {
     PairDesc& d = b->h_pairs[p];

@@ -556,3 +556,38 @@ def test_tabulated_gap_model(direction):
                     assert np.float32(g["score"]).view(np.uint32) == r["score"].view(np.uint32), (p, mode, k)
                     assert np.array_equal(g["pairs"], r["pairs"])
         b.close()
+
+
+def test_batched_subrectangle_fills(blosum62):
+    """Many small sub-matrix builds in ONE launch (what the reference's SSSS loop fill does one DPMatrix at a time,
+    ssss.h:621-631): 40 rectangles over a few sequence pairs, both directions, + Optimal_Subali, against the oracle."""
+    alpha, table = blosum62
+    rng = np.random.RandomState(77)
+    base = [homolog_pair(88000 + n, 120, sub_rate=0.25, indel=4) for n in range(4)]
+    qs, ts, q_idx, t_idx, bounds = [p[0] for p in base], [p[1] for p in base], [], [], []
+    for k in range(40):
+        p = k % 4
+        Q, T = len(qs[p]) + 2, len(ts[p]) + 2
+        q1 = int(rng.randint(0, Q - 3)); q2 = int(rng.randint(q1 + 1, min(Q - 1, q1 + 25) + 1))
+        t1 = int(rng.randint(0, T - 3)); t2 = int(rng.randint(t1 + 1, min(T - 1, t1 + 25) + 1))
+        q_idx.append(p); t_idx.append(p); bounds.append((q1, t1, q2, t2))
+    for direction in ("fwd", "rev"):
+        for mode, gi, ge in ((1, 11, 1), (1, 4.73, 0.34), (4, 11, 1)):
+            b = aln_amd.Batch(gpu_util.ctx(), qs, ts, q_idx, t_idx)
+            b.dp_sub_submatrix(alpha, table, mode, gi, ge, DIRS[direction], bounds)
+            if direction == "fwd":
+                scores, lists, status = b.optimal(subali=True)
+            for k, (q1, t1, q2, t2) in enumerate(bounds):
+                p = q_idx[k]
+                S = orc.sim_submatrix(qs[p], ts[p], alpha, table)
+                rc, D0, PQ0, PT0 = orc.dp_build(S, orc.Gap(mode, gi, ge), orc.FWD if direction == "fwd" else orc.REV,
+                                                bounds=(q1, q2, t1, t2))
+                D, PQ, PT = b.get_cells(k)
+                assert np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (direction, mode, gi, k)
+                assert np.array_equal(PQ, PQ0) and np.array_equal(PT, PT0), (direction, mode, gi, k)
+                if direction == "fwd":
+                    rc2, sc, pairs = orc.optimal(D0, PQ0, PT0, False, sub=(q1, t1, q2, t2))
+                    assert status[k] == rc2
+                    if rc2 == 0:
+                        assert np.float32(scores[k]).view(np.uint32) == sc.view(np.uint32) and np.array_equal(lists[k], pairs)
+            b.close()
