@@ -69,7 +69,12 @@ class HMAPSequence : public Sequence<HMAPElem*> {
   ~HMAPSequence() { for (size_t i = 0; i < size(); ++i) delete (*this)[i]; }
   std::string de_field, sr_field;
   float evd1_field, evd2_field;
-  void getDefaultFlags(SuboptFlags& sof) { for (size_t i = 0; i < size(); ++i) sof.Set((unsigned int)i, true); }
+  // loop positions (p_coil > 0.3) are not suboptimal regions, everything else including the sentinels is (hmapalib_seq.cpp:272-282)
+  void getDefaultFlags(SuboptFlags& sof) {
+    sof.Set(0, true);
+    for (unsigned int i = 1; i <= seq_length; ++i) sof.Set(i, !(at(i)->p_coil() > 0.3f));
+    sof.Set(seq_length + 1, true);
+  }
  protected:
   HMAPSequence() : evd1_field(0), evd2_field(0) {}
   static std::string field(std::istream& in) { std::string k; std::getline(in, k, ':'); return k; }

@@ -69,3 +69,50 @@ def test_aaa_near_optimal_block(mode, gi, ge, tmp_path):
     start = got.index("> templ300")
     assert got[start:start + len(want)] == want
     assert "Ali#=%d" % s["n"] in err
+
+
+def test_nalign2_driver_fasta_block(tmp_path):
+    """nalign2_hip (twin of nalign2.cpp's buildable paths): HMAP profiles in, Hmap2Eval + global DPMatrix + Optimal +
+    ConstrainedNearOptimal over the template's default flags (p_coil > 0.3 -> no branching, hmapalib_seq.cpp:272-282) with
+    NOaliParams defaults (200, 0.01); its FASTA block must be what the oracle's set gives (the reference binary itself needs
+    the Troll library and cannot be built)."""
+    import numpy as np
+    import gpu_util
+    import orc
+    from aln_amd.synth import random_profile
+    from test_gpu_hostcpp import write_hmap
+    exe = os.path.join(ROOT, "alignment-algos_amd", "nalign2_hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "alignment-algos_amd")])
+    qp, tp = random_profile(97000, 41), random_profile(98000, 55)
+    qh = write_hmap(str(tmp_path / "q.hmap"), "query", qp)
+    th = write_hmap(str(tmp_path / "t.hmap"), "templ", tp)
+    env = dict(os.environ, HOME=str(tmp_path))
+    S = orc.hmap2_sim(qh, th, 0.5, 0.12)
+    tgi, tge = orc.hmap2_precalc(th, 4.73, 0.34, 1.0)
+    gap = orc.Gap(4, tgi=tgi, tge=tge)      # AliParams default align_type = semi_local (alib.cpp:16); the DPMatrix itself is built
+    rc, D, PQ, PT = orc.dp_build(S, gap)    # with the constructor's default `global` = not local (nalign2.cpp:84-85)
+    rc2, sc, pairs = orc.optimal(D, PQ, PT, False)
+    T = len(th["conf"])
+    flags = np.ones(T, dtype=np.uint8)
+    flags[1:T - 1] = ~(th["sse"][1:T - 1, 2] > np.float32(0.3))
+    qstr, tstr = "A" * (len(qh["conf"]) - 2), "A" * (T - 2)           # write_hmap names every residue 'A'
+    for args, enumerate_cw in ((["-opt"], False), ([], True)):
+        r = subprocess.run([exe] + args + [str(tmp_path / "q.hmap"), str(tmp_path / "t.hmap")], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr
+        s = orc.AliSet()
+        s.push(pairs, sc)
+        if enumerate_cw:
+            orc.enumerate_noa("cw", D, PQ, PT, S, gap, flags, 200, 0.01, s)
+        s.identity(qstr, tstr)
+        lists = [s.get(k)["pairs"] for k in range(len(s))]
+        tl, qls, idn = gpu_util.strings_for(qstr, tstr, lists)
+        want = ["> templ"] + wrap(tl)
+        for k in range(len(s)):
+            a = s.get(k)
+            want.append("> query_%d %s" % (k, orc.annot(a["score"], a["identity"])))
+            want += wrap(qls[k])
+        got = r.stdout.split("\n")
+        assert got[:len(want)] == want, (args, got[:6], want[:6])
+        if enumerate_cw:
+            assert "Ali#=%d" % len(s) in r.stderr
