@@ -63,3 +63,46 @@ def test_profile_batch_vs_oracle():
             assert status[p] == 0 and np.float32(scores[p]).view(np.uint32) == sc.view(np.uint32)
             assert np.array_equal(lists[p], pairs)
         b.close()
+
+
+def test_full_size_exact_kernels_agree():
+    """BASELINE config-3 size (2000 x 2000 profiles, Hmap2Eval on the device, min(t[t1],t[t2]) gaps): the tiled kernel (shared
+    far-left deletion scans), the slot kernel (per-row scans) and — on a 700-column pair, where it finishes in seconds — the
+    literal O(n^3) kernel are independent programmes for the same arithmetic; planes, scores and paths must be identical."""
+    import os
+
+    def run(qps, tps, env):
+        for k in env:
+            os.environ[k] = "1"
+        try:
+            qpool = {k: np.concatenate([p[k] for p in qps]) for k in ("aa", "sse", "conf")}
+            tpool = {k: np.concatenate([p[k] for p in tps]) for k in ("aa", "sse", "conf")}
+            b = aln_amd.Batch(gpu_util.ctx(), ["A" * (len(p["conf"]) - 2) for p in qps], ["A" * (len(p["conf"]) - 2) for p in tps])
+            b.dp_hmap2(qpool, tpool, 1, 4.73, 0.34, 0.5, 1.0, 0.12)
+            name = b.kernel_name()
+            cells = [b.get_cells(p) for p in range(len(qps))]
+            sc, lists, status = b.optimal()
+            b.close()
+            return name, cells, sc, lists
+        finally:
+            for k in env:
+                del os.environ[k]
+
+    def same(a, c):
+        for p in range(len(a[1])):
+            for x, y in zip(a[1][p], c[1][p]):
+                assert np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32)), (a[0], c[0], p)
+            assert np.array_equal(a[3][p], c[3][p])
+        assert np.array_equal(a[2].view(np.uint32), c[2].view(np.uint32))
+
+    qps = [random_profile(73000, 2000), random_profile(73001, 1990)]
+    tps = [random_profile(74000, 2000), random_profile(74001, 2000)]
+    tiled = run(qps, tps, [])
+    slots = run(qps, tps, ["ALN_EXACT_NO_TILES"])
+    assert "dp_exact_tiled" in tiled[0] and "dp_exact_blocked" in slots[0]
+    same(tiled, slots)
+    qps, tps = [random_profile(73002, 300)], [random_profile(74002, 700)]
+    tiled = run(qps, tps, [])
+    literal = run(qps, tps, ["ALN_EXACT_LITERAL"])
+    assert "dp_exact_tiled" in tiled[0] and literal[0].startswith("dp_exact_kernel")
+    same(tiled, literal)
