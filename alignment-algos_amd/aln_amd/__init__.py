@@ -18,7 +18,7 @@ FWD, REV = 1, 2
 GAP_AFFINE_CONST, GAP_AFFINE_TPOS_MIN, GAP_DEL_TABLE_INS_TPOS, GAP_TABLES = 0, 1, 2, 3
 SIM_SUBMATRIX, SIM_MATRIX, SIM_HMAP2 = 0, 1, 2
 DP_AUTO, DP_EXACT, DP_FAST = 0, 1, 2
-ENUM_CW, ENUM_UCW = 0, 1
+ENUM_CW, ENUM_UCW, ENUM_KSCW = 0, 1, 2
 
 E_BOUNDS, E_GAPSTYLE, E_STARTPAIR, E_RESIDUE, E_ARG, E_HIP, E_NOMEM, E_TOO_LONG, E_NOT_INTEGRAL, E_STATE, E_OVERFLOW = range(-1, -12, -1)
 
@@ -53,7 +53,7 @@ class AlnSim(C.Structure):
 
 class AlnNoa(C.Structure):
     _fields_ = [("kind", C.c_int32), ("number_suboptimal", C.c_int32), ("delta_ratio", C.c_float), ("user_limit", C.c_uint32),
-                ("n_existing", C.c_int32), ("existing_scores", _fp)]
+                ("n_existing", C.c_int32), ("existing_scores", _fp), ("k_limit", C.c_uint32)]
 
 
 class AlnAlignment(C.Structure):
@@ -360,10 +360,13 @@ class Batch:
         _check(lib().aln_batch_get_corner_scores(self.h, _f(s)), self.ctx.h)
         return s
 
-    def enumerate(self, p, kind, number_suboptimal, delta_ratio, flags=None, user_limit=0, max_alignments=None, pairs_capacity=None):
-        """ConstrainedNearOptimal ("cw") / UnconstrainedNearOptimal ("ucw") for pair p -> list of dicts in set order."""
+    def enumerate(self, p, kind, number_suboptimal, delta_ratio, flags=None, user_limit=0, max_alignments=None, pairs_capacity=None,
+                  k_limit=0):
+        """ConstrainedNearOptimal ("cw") / UnconstrainedNearOptimal ("ucw") / KSConstrainedNearOptimal ("kscw") for pair p
+        -> list of dicts in set order."""
         Q, T = self.dims(p)
-        noa = AlnNoa(ENUM_CW if kind == "cw" else ENUM_UCW, int(number_suboptimal), float(np.float32(delta_ratio)), int(user_limit), -1, None)
+        noa = AlnNoa({"cw": ENUM_CW, "ucw": ENUM_UCW, "kscw": ENUM_KSCW}[kind], int(number_suboptimal), float(np.float32(delta_ratio)),
+                     int(user_limit), -1, None, int(k_limit))
         if max_alignments is None:
             max_alignments = max(int(number_suboptimal), 1) + 2
         if pairs_capacity is None:
@@ -388,7 +391,7 @@ class Batch:
                       want_pairs=True, raise_on_overflow=True):
         """aln_batch_enumerate_all: every pair of the batch in one launch.  flags: None, one shared row, or an
         [n, stride] uint8 array.  -> n_out[n], scores[n,K], lengths[n,K], pairs[n,K,stride,2] or None, status[n]"""
-        noa = AlnNoa(ENUM_CW if kind == "cw" else ENUM_UCW, int(number_suboptimal), float(np.float32(delta_ratio)), int(user_limit), -1, None)
+        noa = AlnNoa(ENUM_CW if kind == "cw" else ENUM_UCW, int(number_suboptimal), float(np.float32(delta_ratio)), int(user_limit), -1, None, 0)
         if K is None:
             K = max(int(number_suboptimal), 1) + 2
         fl, fstride = None, 0

@@ -1,0 +1,39 @@
+// enum_common.h — pools and helpers shared by the near-optimal enumeration kernels (enumerate.hip, enumerate_ks.hip).
+#pragma once
+#include "aln_device.h"
+
+namespace aln {
+
+constexpr int kFrameWords = 8;   // q0, t0, k0, cursor, curr_head, curr_score, r, (pad) — one active branch() invocation
+
+struct EnumArgs {
+  int kind;             // ALN_ENUM_CW / ALN_ENUM_UCW
+  uint32_t user_limit;
+  float delta_ratio;
+  int first_slot;       // index of the enumerator's seed alignment inside the set (what is already there stays)
+  // pools (for this pair)
+  uint32_t* node_pair; uint32_t* node_next; uint32_t node_cap;
+  uint32_t* head; float* score; uint32_t ali_cap;
+  uint32_t* stack; uint32_t stack_cap;   // frames of kFrameWords words
+  const uint8_t* flags; // T bytes
+  int ptr_mode;         // pointer word encoding of the P plane
+  int h_mode;           // score plane element type
+  int32_t* out;         // [0] = set size, [1] = nodes used, [2] = status
+  // batched launches (one block per pair): block b works on pair pair0 + b with the b-th slice of every pool
+  int flags_stride;     // bytes between two pairs' flag rows (0: every pair shares one row)
+  // KSConstrainedNearOptimal only
+  uint32_t k_limit;     // NOaliParams::k_limit: operations a branch node may keep
+  int32_t* uid;         // uid of every alignment (kscw.h:121,262)
+  uint32_t cand_cap;    // capacity of the LDS candidate arrays
+};
+
+constexpr uint32_t kNoNode = 0xFFFFFFFFu;
+
+// All mutable pool words are accessed with agent-scope (L2-served) loads/stores: lane 0 writes, every lane reads.
+__device__ __forceinline__ uint32_t ld_u(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_f(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_u(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_f(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+
+}  // namespace aln

@@ -14,36 +14,9 @@
 // the written order (f + r > thr, (f + r) - g > thr, score = r - g).  The host then sorts (score, index)
 // with the same std::sort / std::partial_sort call the reference uses (alignment.h:922-932) and asks the
 // device to unroll only the surviving alignments.
-#include "aln_device.h"
+#include "enum_common.h"
 
 namespace aln {
-
-constexpr int kFrameWords = 8;   // q0, t0, k0, cursor, curr_head, curr_score, r, (pad) — one active branch() invocation
-
-struct EnumArgs {
-  int kind;             // ALN_ENUM_CW / ALN_ENUM_UCW
-  uint32_t user_limit;
-  float delta_ratio;
-  int first_slot;       // index of the enumerator's seed alignment inside the set (what is already there stays)
-  // pools (for this pair)
-  uint32_t* node_pair; uint32_t* node_next; uint32_t node_cap;
-  uint32_t* head; float* score; uint32_t ali_cap;
-  uint32_t* stack; uint32_t stack_cap;   // frames of kFrameWords words
-  const uint8_t* flags; // T bytes
-  int ptr_mode;         // pointer word encoding of the P plane
-  int h_mode;           // score plane element type
-  int32_t* out;         // [0] = set size, [1] = nodes used, [2] = status
-  // batched launches (one block per pair): block b works on pair pair0 + b with the b-th slice of every pool
-  int flags_stride;     // bytes between two pairs' flag rows (0: every pair shares one row)
-};
-
-constexpr uint32_t kNoNode = 0xFFFFFFFFu;
-
-// All mutable pool words are accessed with agent-scope (L2-served) loads/stores: lane 0 writes, every lane reads.
-__device__ __forceinline__ uint32_t ld_u(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_f(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_u(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_f(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __global__ __launch_bounds__(64) void enumerate_kernel(const PairDesc* __restrict__ pairs, int pair, EvalDev proto,
                                                        const uint8_t* __restrict__ qcodes, const uint8_t* __restrict__ tcodes,
@@ -270,6 +243,13 @@ __global__ __launch_bounds__(64) void enum_unroll_kernel(const uint32_t* __restr
 
 }  // namespace aln
 
+namespace aln {
+__global__ void enumerate_ks_kernel(const PairDesc* __restrict__ pairs, int pair, EvalDev proto, const uint8_t* __restrict__ qcodes,
+                                    const uint8_t* __restrict__ tcodes, const float* __restrict__ tgi, const float* __restrict__ tge,
+                                    const float* __restrict__ Hbase, const uint32_t* __restrict__ Pbase,
+                                    const float* __restrict__ Sbase, EnumArgs a);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 #include <algorithm>
 #include <cstdlib>
@@ -288,7 +268,9 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
                                    int32_t max_alignments, int32_t* pairs, int64_t pairs_capacity, int32_t* n_out) {
   if (!b || !noa || !out || !pairs || !n_out || pair < 0 || pair >= b->n_pairs) return ALN_E_ARG;
   if (!b->have_dp || b->have_sub || b->direction != ALN_FWD) return ALN_E_STATE;
-  if (noa->kind == ALN_ENUM_CW && !flags) return ALN_E_ARG;
+  const bool ks = noa->kind == ALN_ENUM_KSCW;
+  if ((noa->kind == ALN_ENUM_CW || ks) && !flags) return ALN_E_ARG;
+  if (noa->kind != ALN_ENUM_CW && noa->kind != ALN_ENUM_UCW && !ks) return ALN_E_ARG;
   aln_ctx* ctx = b->ctx;
   ALN_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const PairDesc& d = b->h_pairs[pair];
@@ -315,13 +297,16 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   a.user_limit = user_limit;
   a.delta_ratio = noa->delta_ratio;
   a.first_slot = n_ex;
+  a.k_limit = ks ? (noa->k_limit ? noa->k_limit : 16u) : 0u;
+  if (a.k_limit > 64u) return ALN_E_ARG;
+  a.cand_cap = (uint32_t)(d.Q + d.T);
   a.ali_cap = user_limit + 65536u + (uint32_t)n_ex;
   a.node_cap = 48u << 20;
   if (const char* env = getenv("ALN_ENUM_NODE_CAP")) a.node_cap = (uint32_t)strtoul(env, nullptr, 10);
   a.stack_cap = (uint32_t)(d.Q + d.T + 8);
   uint8_t* d_flags = nullptr; int32_t* d_out = nullptr;
   auto cleanup = [&]() {
-    hipFree(a.node_pair); hipFree(a.node_next); hipFree(a.head); hipFree(a.score); hipFree(a.stack);
+    hipFree(a.node_pair); hipFree(a.node_next); hipFree(a.head); hipFree(a.score); hipFree(a.stack); hipFree(a.uid);
     hipFree(d_flags); hipFree(d_out);
   };
 #define ETRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup(); return ALN_E_HIP; } } while (0)
@@ -329,7 +314,8 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   ETRY(hipMalloc((void**)&a.node_next, (size_t)a.node_cap * 4));
   ETRY(hipMalloc((void**)&a.head, (size_t)a.ali_cap * 4));
   ETRY(hipMalloc((void**)&a.score, (size_t)a.ali_cap * 4));
-  ETRY(hipMalloc((void**)&a.stack, (size_t)a.stack_cap * kFrameWords * 4));
+  ETRY(hipMalloc((void**)&a.stack, (size_t)a.stack_cap * (ks ? 8 + 4 * a.k_limit : kFrameWords) * 4));
+  if (ks) ETRY(hipMalloc((void**)&a.uid, (size_t)a.ali_cap * 4));
   ETRY(hipMalloc((void**)&d_flags, (size_t)d.T));
   ETRY(hipMalloc((void**)&d_out, 16));
   if (flags) ETRY(hipMemcpyAsync(d_flags, flags, (size_t)d.T, hipMemcpyHostToDevice, ctx->stream));
@@ -347,6 +333,11 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   proto.tcn = b->d_tcn; proto.deltab = b->d_deltab; proto.deltab_off = b->d_deltab_off; proto.instab = b->d_instab;
   const bool sub = b->sim_kind == ALN_SIM_SUBMATRIX;
   const bool tpos = b->gapdev.model != ALN_GAP_AFFINE_CONST;
+  if (ks)
+    hipLaunchKernelGGL(enumerate_ks_kernel, dim3(1), dim3(64), (size_t)a.cand_cap * 8, ctx->stream, b->d_pairs, pair, proto,
+                       sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr,
+                       b->d_H, b->d_P, sub ? nullptr : b->d_S, a);
+  else
   hipLaunchKernelGGL(enumerate_kernel, dim3(1), dim3(64), 0, ctx->stream, b->d_pairs, pair, proto, sub ? b->d_qcodes : nullptr,
                      sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr, b->d_H, b->d_P,
                      sub ? nullptr : b->d_S, a);
@@ -361,6 +352,11 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   ETRY(hipStreamSynchronize(ctx->stream));
   if (seed_opt) scores[0] = b->islocal ? res[pair].best : res[pair].corner;
   else for (int k = 0; k < n_ex; ++k) scores[k] = noa->existing_scores[k];
+  std::vector<int32_t> uids;
+  if (ks) {
+    uids.assign(n_as, -1);
+    ETRY(hipMemcpy(uids.data() + n_ex, a.uid + n_ex, (size_t)(n_as - n_ex) * 4, hipMemcpyDeviceToHost));
+  }
 
   // AlignmentSet::sortSet(number_suboptimal) — alignment.h:922-932, same libstdc++ calls on the same order of keys
   std::vector<SortKey> keys(n_as);
@@ -423,7 +419,7 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
     if (off + len > pairs_capacity) return ALN_E_OVERFLOW;
     memcpy(pairs + 2 * off, src, (size_t)len * 8);
     out[k].score = keys[k].score;
-    out[k].uid = (idx < n_ex) ? -1 : (noa->kind == ALN_ENUM_CW ? 0 : -1);   // cw.h:83 sets uid 0 on its seed; copies inherit it
+    out[k].uid = (idx < n_ex) ? -1 : ks ? uids[idx] : (noa->kind == ALN_ENUM_CW ? 0 : -1);   // cw.h:83 sets uid 0 on its seed; copies inherit it
     out[k].n_pairs = len;
     out[k].pair_off = off;
     out[k].identity = aln_identity(qs.c_str(), d.Q, ts.c_str(), d.T, pairs + 2 * off, len);

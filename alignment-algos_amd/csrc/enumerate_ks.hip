@@ -1,0 +1,342 @@
+// enumerate_ks.hip — K-sorted constrained near-optimal enumeration on the resident DP planes (gfx950).
+//
+// Reference: KSConstrainedNearOptimal (kscw.h:109-351).  Like ConstrainedNearOptimal (enumerate.hip) it branches where the
+// template's SuboptFlags bit flips, but a branch node first collects EVERY predecessor that passes Waterman's condition
+// (match, row q0-1 for i = t0-2..1, column t0-1 for j = q0-2..1), sorts the operations by f + r - g (std::sort, or
+// std::partial_sort when there are more than the node's limit), keeps the limit best, gives the best one the node's own limit
+// and the others half of it, and lets an operation whose limit has fallen to 1 only follow stored pointers.
+//
+// kscw.h cannot be compiled on this platform (min(size_t, unsigned) at :188; debug operator<< for Troll-only types), so there
+// is no golden for this kernel: it is checked against the oracle's restatement of the source (parity UNPINNED).
+//
+// Device form: one wave per pair, the trie / (head, score) representation and the diagonal-run walk of enumerate.hip.  The
+// candidate scan is 64-wide with ballot compaction into LDS arrays (sum, candidate index) in the reference's order; the sort
+// is libstdc++'s own algorithm (introsort + final insertion sort / heap select + sort_heap, GCC 11 bits/stl_algo.h,
+// stl_heap.h) restated for one lane on those arrays, because the order of equal scores is observable in the result.
+#include "enum_common.h"
+
+namespace aln {
+
+namespace kssort {
+// element i = (sc[i], ix[i]); comp(a, b) = a.score > b.score   (kscw.h:44-45)
+struct Arr {
+  float* sc; int* ix;
+  __device__ __forceinline__ bool lt(int a, int b) const { return sc[a] > sc[b]; }
+  __device__ __forceinline__ void swap(int a, int b) { float s = sc[a]; sc[a] = sc[b]; sc[b] = s; int i = ix[a]; ix[a] = ix[b]; ix[b] = i; }
+  __device__ __forceinline__ void move(int dst, int src) { sc[dst] = sc[src]; ix[dst] = ix[src]; }
+};
+// stl_heap.h __push_heap / __adjust_heap (value passed separately)
+__device__ inline void adjust_heap(Arr a, int first, int hole, int len, float vs, int vi) {
+  const int top = hole;
+  int second = hole;
+  while (second < (len - 1) / 2) {
+    second = 2 * (second + 1);
+    if (a.lt(first + second, first + (second - 1))) second--;
+    a.move(first + hole, first + second);
+    hole = second;
+  }
+  if ((len & 1) == 0 && second == (len - 2) / 2) {
+    second = 2 * (second + 1);
+    a.move(first + hole, first + (second - 1));
+    hole = second - 1;
+  }
+  int parent = (hole - 1) / 2;                                   // __push_heap
+  while (hole > top && a.sc[first + parent] > vs) {
+    a.move(first + hole, first + parent);
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  a.sc[first + hole] = vs; a.ix[first + hole] = vi;
+}
+__device__ inline void make_heap(Arr a, int first, int last) {
+  const int len = last - first;
+  if (len < 2) return;
+  int parent = (len - 2) / 2;
+  while (true) {
+    const float vs = a.sc[first + parent]; const int vi = a.ix[first + parent];
+    adjust_heap(a, first, parent, len, vs, vi);
+    if (parent == 0) return;
+    parent--;
+  }
+}
+__device__ inline void pop_heap(Arr a, int first, int last, int result) {
+  const float vs = a.sc[result]; const int vi = a.ix[result];
+  a.move(result, first);
+  adjust_heap(a, first, 0, last - first, vs, vi);
+}
+__device__ inline void heap_select(Arr a, int first, int middle, int last) {
+  make_heap(a, first, middle);
+  for (int i = middle; i < last; ++i)
+    if (a.lt(i, first)) pop_heap(a, first, middle, i);
+}
+__device__ inline void sort_heap(Arr a, int first, int last) {
+  while (last - first > 1) { --last; pop_heap(a, first, last, last); }
+}
+__device__ inline void partial_sort(Arr a, int first, int middle, int last) {   // std::partial_sort
+  heap_select(a, first, middle, last);
+  sort_heap(a, first, middle);
+}
+__device__ inline void unguarded_linear_insert(Arr a, int last) {
+  const float vs = a.sc[last]; const int vi = a.ix[last];
+  int next = last - 1;
+  while (vs > a.sc[next]) { a.move(last, next); last = next; --next; }
+  a.sc[last] = vs; a.ix[last] = vi;
+}
+__device__ inline void insertion_sort(Arr a, int first, int last) {
+  if (first == last) return;
+  for (int i = first + 1; i != last; ++i) {
+    if (a.lt(i, first)) {
+      const float vs = a.sc[i]; const int vi = a.ix[i];
+      for (int k = i; k > first; --k) a.move(k, k - 1);          // move_backward(first, i, i + 1)
+      a.sc[first] = vs; a.ix[first] = vi;
+    } else unguarded_linear_insert(a, i);
+  }
+}
+__device__ inline void move_median_to_first(Arr a, int result, int x, int y, int z) {
+  if (a.lt(x, y)) {
+    if (a.lt(y, z)) a.swap(result, y);
+    else if (a.lt(x, z)) a.swap(result, z);
+    else a.swap(result, x);
+  } else if (a.lt(x, z)) a.swap(result, x);
+  else if (a.lt(y, z)) a.swap(result, z);
+  else a.swap(result, y);
+}
+__device__ inline int unguarded_partition(Arr a, int first, int last, int pivot) {
+  while (true) {
+    while (a.lt(first, pivot)) ++first;
+    --last;
+    while (a.lt(pivot, last)) --last;
+    if (!(first < last)) return first;
+    a.swap(first, last);
+    ++first;
+  }
+}
+// std::sort: __introsort_loop (ranges on an explicit stack; the two halves are independent) + __final_insertion_sort
+__device__ inline void sort(Arr a, int first, int last) {
+  if (first == last) return;
+  int n = last - first, lg = 0;
+  while ((n >> (lg + 1)) > 0) ++lg;                              // std::__lg
+  int stf[64], stl[64], std_[64], sp = 0;
+  stf[0] = first; stl[0] = last; std_[0] = 2 * lg; sp = 1;
+  while (sp > 0) {
+    --sp;
+    int f = stf[sp], l = stl[sp], depth = std_[sp];
+    while (l - f > 16) {
+      if (depth == 0) { partial_sort(a, f, l, l); break; }
+      --depth;
+      const int mid = f + (l - f) / 2;
+      move_median_to_first(a, f, f + 1, mid, l - 1);
+      const int cut = unguarded_partition(a, f + 1, l, f);
+      if (sp < 64) { stf[sp] = cut; stl[sp] = l; std_[sp] = depth; ++sp; }
+      l = cut;
+    }
+  }
+  if (last - first > 16) {
+    insertion_sort(a, first, first + 16);
+    for (int i = first + 16; i != last; ++i) unguarded_linear_insert(a, i);
+  } else insertion_sort(a, first, last);
+}
+}  // namespace kssort
+
+__global__ __launch_bounds__(64) void enumerate_ks_kernel(const PairDesc* __restrict__ pairs, int pair, EvalDev proto,
+                                                          const uint8_t* __restrict__ qcodes, const uint8_t* __restrict__ tcodes,
+                                                          const float* __restrict__ tgi, const float* __restrict__ tge,
+                                                          const float* __restrict__ Hbase, const uint32_t* __restrict__ Pbase,
+                                                          const float* __restrict__ Sbase, EnumArgs a) {
+  extern __shared__ float ks_lds[];
+  float* csc = ks_lds;                                           // candidate sums
+  int* cix = reinterpret_cast<int*>(ks_lds + a.cand_cap);        // candidate indices (position in the reference's scan order)
+  const PairDesc pd = pairs[pair];
+  EvalDev e = proto;
+  e.Q = pd.Q; e.T = pd.T; e.ld = pd.ld;
+  e.qc = qcodes ? qcodes + pd.q_off : nullptr;
+  e.tc = tcodes ? tcodes + pd.t_off : nullptr;
+  e.tgi = tgi ? tgi + pd.t_off : nullptr;
+  e.tge = tge ? tge + pd.t_off : nullptr;
+  bind_table_model(e, proto, pd);
+  e.S = Sbase ? Sbase + pd.plane_off : nullptr;
+  auto HV = [&](int i, int j) -> float { return load_score(Hbase, pd.plane_off, pd.ld, i, j, a.h_mode); };
+  const int ld = pd.ld, lane = threadIdx.x;
+  const int Q = pd.Q, T = pd.T;
+  const int FW = 8 + 4 * (int)a.k_limit;                         // frame: q0 t0 k0 nops cursor curr_head curr_score - | ops (pq, pt, new_r, limit)
+
+  uint32_t n_as = (uint32_t)a.first_slot + 1;                    // as.push_back(SingleAlignment())  kscw.h:120
+  uint32_t n_nodes = 0;
+  int status = 0;
+  auto sync_mem = [&]() { __builtin_amdgcn_s_waitcnt(0); };
+  if (lane == 0) { st_u(&a.head[a.first_slot], kNoNode); st_f(&a.score[a.first_slot], 0.f); a.uid[a.first_slot] = 1; }   // uid = 1, :121
+  sync_mem();
+
+  const float top = HV(Q - 1, T - 1);
+  float thr = (1.f - a.delta_ratio) * top;                       // kscw.h:124-126
+  { float alt = top - 0.1f; thr = (alt < thr) ? alt : thr; }
+
+  auto prepend = [&](int k, int q, int t) {
+    if (n_nodes >= a.node_cap) { status = ALN_E_OVERFLOW; return; }
+    if (lane == 0) {
+      a.node_pair[n_nodes] = ((uint32_t)q << 16) | (uint32_t)t;
+      a.node_next[n_nodes] = ld_u(&a.head[k]);
+      st_u(&a.head[k], n_nodes);
+    }
+    ++n_nodes;
+    sync_mem();
+  };
+  auto base_case = [&](int q0, int t0, int k0) {                 // kscw.h:147-155 / :308-316
+    prepend(k0, q0, t0);
+    prepend(k0, 0, 0);
+    float s = ld_f(&a.score[k0]);
+    s += HV(q0, t0);
+    if (lane == 0) st_f(&a.score[k0], s);
+    sync_mem();
+  };
+  // the pointer-following loop of opt_path (kscw.h:329-348), 64 cells of a diagonal at a time (see enumerate.hip)
+  auto walk = [&](int& q0, int& t0, int k0, bool force) {
+    const bool flag = !a.flags[t0];
+    float sc = ld_f(&a.score[k0]);
+    uint32_t hd = ld_u(&a.head[k0]);
+    while (t0 > 1 && q0 > 1 && status == 0) {
+      const int q = q0 - lane, t = t0 - lane;
+      bool stop = !(q > 1 && t > 1);
+      if (!stop && !force && ((a.flags[t] != 0) == flag)) stop = true;
+      int pq = 0, pt = 0; float sv = 0.f, g = 0.f;
+      if (!stop) {
+        const uint32_t p = load_ptr_word(Pbase, pd.plane_off, ld, q, t, a.ptr_mode);
+        decode_ptr(p, a.ptr_mode, q, t, pq, pt);
+        sv = dev_sim(e, q, t);
+      }
+      const bool diag = !stop && pq == q - 1 && pt == t - 1;
+      const unsigned long long m_end = __ballot(!diag);
+      const int F = m_end ? __builtin_ctzll(m_end) : 64;
+      const bool gap_cell = F < 64 && !(((__ballot(stop)) >> F) & 1ull);
+      const int n_proc = gap_cell ? F + 1 : F;
+      if (n_proc == 0) break;
+      if (n_nodes + (uint32_t)n_proc > a.node_cap) { status = ALN_E_OVERFLOW; break; }
+      if (lane < n_proc) {
+        a.node_pair[n_nodes + lane] = ((uint32_t)q << 16) | (uint32_t)t;
+        a.node_next[n_nodes + lane] = lane == 0 ? hd : n_nodes + lane - 1;
+      }
+      hd = n_nodes + n_proc - 1;
+      n_nodes += n_proc;
+      if (gap_cell && lane == F) {
+        if (q - pq == 1) g = dev_deletion(e, pt, t);
+        else g = dev_insertion(e, pq, q, pt, t);
+      }
+      for (int l = 0; l < n_proc; ++l) sc += __shfl(sv, l);
+      if (gap_cell) {
+        sc -= __shfl(g, F);
+        q0 = __shfl(pq, F); t0 = __shfl(pt, F);
+      } else { q0 -= n_proc; t0 -= n_proc; }
+    }
+    if (lane == 0) { st_u(&a.head[k0], hd); st_f(&a.score[k0], sc); }
+    sync_mem();
+  };
+
+  enum { CALL_NONE = 0, CALL_BRANCH = 1, CALL_OPT = 2 };
+  int call = CALL_BRANCH, cq = Q - 1, ct = T - 1, ck = a.first_slot; bool cforce = false;
+  uint32_t climit = a.k_limit;
+  int sp = 0;
+  long guard = 0;
+  while ((call != CALL_NONE || sp > 0) && status == 0) {
+    if (++guard > (1L << 36)) { status = ALN_E_OVERFLOW; break; }
+    if (call == CALL_OPT) {                                      // opt_path, kscw.h:291-351
+      call = CALL_NONE;
+      int q0 = cq, t0 = ct; const int k0 = ck; bool force = cforce;
+      if (climit <= 1) force = true;
+      if (q0 == 1 || t0 == 1) { base_case(q0, t0, k0); continue; }
+      walk(q0, t0, k0, force);
+      call = CALL_BRANCH; cq = q0; ct = t0; ck = k0;             // branch(op(k_limit, pq, pt, k0)), :344-346
+      continue;
+    }
+    if (call == CALL_BRANCH) {                                   // branch, kscw.h:139-288
+      call = CALL_NONE;
+      const int q0 = cq, t0 = ct, k0 = ck;
+      const uint32_t k_limit = climit;
+      if (q0 == 1 || t0 == 1) { base_case(q0, t0, k0); continue; }
+      if (q0 < 1 || t0 < 1) { status = ALN_E_ARG; break; }       // the reference would index row / column -1
+      if (n_as > a.user_limit) { call = CALL_OPT; cforce = true; continue; }   // :168-180 (same op)
+      if ((uint32_t)sp >= a.stack_cap) { status = ALN_E_OVERFLOW; break; }
+      const uint32_t ch = ld_u(&a.head[k0]);
+      const float cs = ld_f(&a.score[k0]);
+      const float r = cs + dev_sim(e, q0, t0);
+      // ---- every candidate that passes Waterman's condition, in the reference's order, into LDS -----------------------
+      const int ndel = t0 - 2, nins = q0 - 2;
+      const int ncand = 1 + ndel + nins;
+      int n = 0;
+      for (int base = 0; base < ncand; base += 64) {
+        const int idx = base + lane;
+        bool ok = false; float sum = 0.f;
+        if (idx < ncand) {
+          if (idx == 0) { sum = HV(q0 - 1, t0 - 1) + r; }
+          else if (idx <= ndel) { const int pt = t0 - 1 - idx; sum = HV(q0 - 1, pt) + r - dev_deletion(e, pt, t0); }
+          else { const int pq = q0 - 2 - (idx - ndel - 1); sum = HV(pq, t0 - 1) + r - dev_insertion(e, pq, q0, t0 - 1, t0); }
+          ok = sum > thr;
+        }
+        const unsigned long long m = __ballot(ok);
+        if (m) {
+          const int pos = n + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+          if (ok && pos < (int)a.cand_cap) { csc[pos] = sum; cix[pos] = idx; }
+          n += __builtin_popcountll(m);
+        }
+      }
+      if (n > (int)a.cand_cap) { status = ALN_E_OVERFLOW; break; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (n == 0) { call = CALL_OPT; climit = 1; cforce = true; continue; }    // :222-228: op(1, q0, t0, k0), forced
+      // ---- sort, keep the k_limit best (kscw.h:232-241) ------------------------------------------------------------------
+      int m_keep = n;
+      if (lane == 0) {
+        kssort::Arr arr = {csc, cix};
+        if ((uint32_t)n > k_limit) kssort::partial_sort(arr, 0, (int)k_limit, n);
+        else kssort::sort(arr, 0, n);
+      }
+      if ((uint32_t)n > k_limit) m_keep = (int)k_limit;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (m_keep == 0) { status = ALN_E_ARG; break; }            // limit 0 with candidates: `it->limit *= 2` on an empty vector in the reference
+      // ---- the frame: operations in sorted order --------------------------------------------------------------------
+      uint32_t* f = a.stack + (size_t)sp * FW;
+      if (lane < m_keep) {
+        const int idx = cix[lane];
+        int pq, pt; float nr;
+        if (idx == 0) { pq = q0 - 1; pt = t0 - 1; nr = r; }
+        else if (idx <= ndel) { pq = q0 - 1; pt = t0 - 1 - idx; nr = r - dev_deletion(e, pt, t0); }
+        else { pq = q0 - 2 - (idx - ndel - 1); pt = t0 - 1; nr = r - dev_insertion(e, pq, q0, pt, t0); }
+        uint32_t lim = k_limit / 2;
+        if (lane == 0) lim *= 2;                                 // only the best operation keeps (about) the node's limit, :246-247
+        uint32_t* op = f + 8 + 4 * lane;
+        st_u(op + 0, (uint32_t)pq); st_u(op + 1, (uint32_t)pt); st_u(op + 2, __float_as_uint(nr)); st_u(op + 3, lim);
+      }
+      if (lane == 0) {
+        st_u(f + 0, (uint32_t)q0); st_u(f + 1, (uint32_t)t0); st_u(f + 2, (uint32_t)k0); st_u(f + 3, (uint32_t)m_keep);
+        st_u(f + 4, 0u); st_u(f + 5, ch); st_u(f + 6, __float_as_uint(cs));
+      }
+      sync_mem();
+      ++sp;
+      continue;
+    }
+    // ---- resume the frame on top of the stack: the next sorted operation (kscw.h:250-262) ------------------------------
+    uint32_t* f = a.stack + (size_t)(sp - 1) * FW;
+    const int q0 = (int)ld_u(f + 0), t0 = (int)ld_u(f + 1), k0 = (int)ld_u(f + 2), nops = (int)ld_u(f + 3), cursor = (int)ld_u(f + 4);
+    if (cursor >= nops) { --sp; continue; }
+    const uint32_t curr_head = ld_u(f + 5);
+    const float curr_score = __uint_as_float(ld_u(f + 6));
+    const uint32_t* op = f + 8 + 4 * cursor;
+    const int pq = (int)ld_u(op + 0), pt = (int)ld_u(op + 1);
+    const float nr = __uint_as_float(ld_u(op + 2));
+    const uint32_t lim = ld_u(op + 3);
+    const int k = (cursor == 0) ? k0 : (int)n_as;
+    if ((uint32_t)k == n_as) {                                   // as.push_back(curr); as[k].uid = k
+      if (n_as >= a.ali_cap) { status = ALN_E_OVERFLOW; break; }
+      if (lane == 0) { st_u(&a.head[n_as], curr_head); st_f(&a.score[n_as], curr_score); a.uid[n_as] = (int32_t)n_as; }
+      sync_mem();
+      ++n_as;
+    }
+    prepend(k, q0, t0);
+    if (lane == 0) { st_f(&a.score[k], nr); st_u(f + 4, (uint32_t)(cursor + 1)); }
+    sync_mem();
+    call = CALL_OPT; cq = pq; ct = pt; ck = k; climit = lim; cforce = false;
+  }
+  if (lane == 0) { a.out[0] = (int32_t)n_as; a.out[1] = (int32_t)n_nodes; a.out[2] = status; }
+}
+
+}  // namespace aln

@@ -26,6 +26,7 @@ void run_enumeration(int kind, const NOaliParams& params, const unsigned char* f
   noa.user_limit = user_limit;
   noa.n_existing = n_existing;
   noa.existing_scores = ex.data();
+  noa.k_limit = params.k_limit;
   const int per = std::min(dpm.getQuerySize(), dpm.getTemplateSize()) + 3;
   int32_t cap = std::max(params.number_suboptimal, 1) + n_existing + 1, n_out = 0;
   std::vector<aln_alignment> out;

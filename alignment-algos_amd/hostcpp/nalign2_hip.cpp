@@ -3,8 +3,8 @@
 // template's default flags (loops excluded) or a flag file, or UnconstrainedNearOptimal (-ucw); FASTA or PIR output.
 // Same flags and parameter handling as the reference driver.  Differences: the template is read as an HMAP profile (the
 // reference's SMAPSequence also loads a PDB structure through the Troll library, which Hmap2Eval never looks at);
-// -kscw / -crcw (the reference's experimental enumerators, not buildable on LP64 — DESIGN.md section 5) and the HMAP output
-// format are refused.  The reference binary cannot be built here, so this driver's stdout has no golden; its pieces
+// -crcw (experimental, reads out of bounds in the reference: crcw.h:366-402) and the HMAP output format are refused; -kscw runs
+// the engine's KSConstrainedNearOptimal (parity unpinned).  The reference binary cannot be built here, so this driver's stdout has no golden; its pieces
 // (HMAP parser, Hmap2Eval, DPMatrix, Optimal, cw, writers) are each checked against the oracle / real reference.
 #include <ctime>
 #include <fstream>
@@ -17,6 +17,7 @@
 #include "fastaio.h"
 #include "formats.h"
 #include "hmap2_eval.h"
+#include "kscw.h"
 #include "optimal.h"
 #include "pirio.h"
 #include "rcfile.h"
@@ -31,6 +32,7 @@ static void usage() {
   cerr << "   template.flag  specify regions for suboptimal alignment" << endl;
   cerr << "   -opt           just do an optimal alignment (-ucw & template.flag are ignored)" << endl;
   cerr << "   -ucw           do standard waterman suboptimal alignment (template.flag is ignored)" << endl;
+  cerr << "   -kscw          constrained enumeration with k-sorted branching" << endl;
   cerr << "   -top <file>    specify a parameter file" << endl;
   cerr << "      --PARAMETER_NAME value   overrides a parameter" << endl << endl;
   exit(0);
@@ -48,7 +50,7 @@ int main(int argc, const char** argv) {
     bool ucwflag = args.getSwitch("-ucw", true);
     bool kscwflag = args.getSwitch("-kscw", true);
     bool crcwflag = args.getSwitch("-crcw", true);
-    if (kscwflag || crcwflag) throw string("-kscw / -crcw: these experimental enumerators are not available on this engine");
+    if (crcwflag) throw string("-crcw: this experimental enumerator is not available on this engine");
 
     Gn2Params ali_params;
     ApplicationParams app_params;
@@ -81,6 +83,16 @@ int main(int argc, const char** argv) {
         cerr << "Now adding unconstrained suboptimal alignments." << endl;
         UnconstrainedNearOptimal<HMAPSequence, SMAPSequence, Hmap2Eval> ucw(ali_params);
         ucw.enumerate(dpm, alignments);
+      } else if (kscwflag) {
+        cerr << "Now adding constrained suboptimal alignments, with branching limited by k-sort." << endl;
+        SuboptFlags subopt(true, templ.size());
+        templ.getDefaultFlags(subopt);
+        if (args.count() > 2) {
+          ifstream fin(args.getArg(2).str().c_str());
+          fin >> Formats::FastaIn("Flags=suboptimal region", false) >> subopt;
+        }
+        KSConstrainedNearOptimal<HMAPSequence, SMAPSequence, Hmap2Eval> kscno(ali_params, subopt);
+        kscno.enumerate(dpm, alignments);
       } else {
         cerr << "Now adding constrained suboptimal alignments." << endl;
         SuboptFlags subopt(true, templ.size());

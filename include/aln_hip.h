@@ -56,7 +56,9 @@ enum aln_dp_algo {
 
 enum aln_enum_kind {
   ALN_ENUM_CW = 0,              /* ConstrainedNearOptimal, cw.h:68-284 */
-  ALN_ENUM_UCW = 1              /* UnconstrainedNearOptimal, ucw.h:64-236 */
+  ALN_ENUM_UCW = 1,             /* UnconstrainedNearOptimal, ucw.h:64-236 */
+  ALN_ENUM_KSCW = 2             /* KSConstrainedNearOptimal, kscw.h:109-351 (aln_batch_enumerate only; parity unpinned: the reference
+                                   header does not compile on LP64) */
 };
 
 enum aln_status {
@@ -146,6 +148,8 @@ typedef struct {
                                    >= 0: the caller's AlignmentSet already holds this many alignments (enumerate() appends) */
   const float* existing_scores; /* their scores (they take part in sortSet); such entries come back with n_pairs = -1
                                    and pair_off = their old index */
+  uint32_t k_limit;             /* KSCW: operations a branch node keeps (NOaliParams::k_limit, default 16); its user_limit is
+                                   NOaliParams::user_limit (0 = the default 100000, noalib.cpp:20) */
 } aln_noa;
 
 /* One alignment as the enumerators return it (AlignedPairList, alignment.h:52-113). */

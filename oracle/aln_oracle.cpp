@@ -701,6 +701,92 @@ struct Enum {
     }
     if (k == k0) opt_path_ucw(q0, t0, k0);
   }
+
+  // ---- KSConstrainedNearOptimal (kscw.h:109-351): every branch node keeps only its k_limit best operations -------------
+  struct op_data {                                         // kscw.h:38-46
+    unsigned int limit;
+    int q0, t0, k0;
+    float score, thresh, new_r;
+    op_data(unsigned int l, int q, int t, int k, float th, float s = 0.f, float n = 0.f)
+        : limit(l), q0(q), t0(t), k0(k), score(s), thresh(th), new_r(n) {}
+    bool operator<(const op_data& a) const { return score > a.score; }
+  };
+
+  // kscw.h:291-351
+  void opt_path_ks(op_data& op, bool force_opt) {
+    unsigned int k_limit = op.limit;
+    int q0 = op.q0, t0 = op.t0, k0 = op.k0;
+    float threshold = op.thresh;
+    if (k_limit <= 1) force_opt = true;
+    if (q0 == 1 || t0 == 1) { base_case(q0, t0, k0); return; }
+    int pq = -1, pt = -1;
+    bool flag = !flags[t0];
+    while (t0 > 1 && q0 > 1) {
+      if (!force_opt && (flags[t0] != 0) == flag) break;
+      (*as)[k0].prepend(q0, t0);
+      (*as)[k0].score += S[q0 * T + t0];
+      pq = PQ[q0 * T + t0];
+      pt = PT[q0 * T + t0];
+      float g;
+      if (q0 - pq == 1) g = del(pq, q0, pt, t0);
+      else g = ins(pq, q0, pt, t0);
+      (*as)[k0].score -= g;
+      t0 = pt; q0 = pq;
+    }
+    op_data nop(k_limit, pq, pt, k0, threshold);
+    branch_ks(nop);
+  }
+
+  // kscw.h:139-288
+  void branch_ks(op_data& op) {
+    unsigned int k_limit = op.limit;
+    int q0 = op.q0, t0 = op.t0, k0 = op.k0;
+    float threshold = op.thresh;
+    if (q0 == 1 || t0 == 1) { base_case(q0, t0, k0); return; }
+    if (q0 < 1 || t0 < 1) { err = ORC_E_ARG; return; }     // the reference would index row/column -1 here
+    float f, r, g, sum;
+    OrcAli curr((*as)[k0]);
+    std::vector<op_data> k_sort;
+    k_sort.reserve(q0 + t0);
+    if (as->size() > user_limit) { opt_path_ks(op, true); return; }
+    r = curr.score + S[q0 * T + t0];
+    f = d(q0 - 1, t0 - 1);
+    sum = f + r;
+    if (sum > threshold) k_sort.push_back(op_data(k_limit / 2, q0 - 1, t0 - 1, k0, threshold, sum, r));
+    for (int i = t0 - 2; i > 0; --i) {
+      f = d(q0 - 1, i);
+      g = del(q0 - 1, q0, i, t0);
+      sum = f + r - g;
+      if (sum > threshold) k_sort.push_back(op_data(k_limit / 2, q0 - 1, i, k0, threshold, sum, r - g));
+    }
+    for (int j = q0 - 2; j > 0; --j) {
+      f = d(j, t0 - 1);
+      g = ins(j, q0, t0 - 1, t0);
+      sum = f + r - g;
+      if (sum > threshold) k_sort.push_back(op_data(k_limit / 2, j, t0 - 1, k0, threshold, sum, r - g));
+    }
+    if (k_sort.size() == 0) {
+      op_data new_op(1, q0, t0, k0, threshold);
+      opt_path_ks(new_op, true);
+      return;
+    }
+    if (k_sort.size() > k_limit) {
+      std::partial_sort(k_sort.begin(), k_sort.begin() + k_limit, k_sort.end());
+      k_sort.erase(k_sort.begin() + k_limit, k_sort.end());
+    } else {
+      std::sort(k_sort.begin(), k_sort.end());
+    }
+    std::vector<op_data>::iterator it = k_sort.begin();
+    it->limit *= 2;                                        // only the best operation keeps the node's own limit
+    for (int k = k0; it != k_sort.end(); ++it) {
+      it->k0 = k;
+      if ((int)as->size() == k) { as->push_back(curr); (*as)[k].uid = k; }
+      (*as)[k].prepend(q0, t0);
+      (*as)[k].score = it->new_r;
+      opt_path_ks(*it, false);
+      k = (int)as->size();
+    }
+  }
 };
 
 }  // namespace
@@ -724,8 +810,32 @@ int orc_enumerate(int kind, int Q, int T, const float* D, const int* PQ, const i
   float threshold = (1.f - delta_ratio) * top;
   threshold = std::min(threshold, top - 0.1f);
   e.thr = threshold;
+  if (kind != 0 && kind != 1) return ORC_E_ARG;            // KSConstrainedNearOptimal has its own entry point
   if (kind == 0) e.branch_cw(q_last, t_last, k_last, false);
   else e.branch_ucw(q_last, t_last, k_last);
+  orc_set_sort(as, number_suboptimal);
+  return e.err;
+}
+
+// KSConstrainedNearOptimal::enumerate (kscw.h:109-136).  Parity UNPINNED: kscw.h does not compile on LP64 (:188) and its debug
+// operator<< ties it to Troll-dependent types; this restates the source as written.
+int orc_enumerate_ks(int Q, int T, const float* D, const int* PQ, const int* PT, const float* S, const orc_gap* gap,
+                     const unsigned char* flags, int number_suboptimal, float delta_ratio, unsigned k_limit, unsigned user_limit,
+                     orc_set* as) {
+  Enum e;
+  e.kind = 2; e.Q = Q; e.T = T; e.D = D; e.PQ = PQ; e.PT = PT; e.S = S; e.gap = gap;
+  e.flags = flags; e.as = &as->v; e.err = 0;
+  e.user_limit = user_limit;             // NOaliParams::user_limit (default 100000, noalib.cpp:20); not hard-wired here
+  int q_last = Q - 1, t_last = T - 1;
+  OrcAli seed;
+  seed.uid = 1;                          // kscw.h:121
+  as->v.push_back(seed);
+  int k_last = (int)as->v.size() - 1;
+  float top = D[q_last * T + t_last];
+  float threshold = (1.f - delta_ratio) * top;
+  threshold = std::min(threshold, top - 0.1f);
+  Enum::op_data op(k_limit, q_last, t_last, k_last, threshold);
+  e.branch_ks(op);
   orc_set_sort(as, number_suboptimal);
   return e.err;
 }

@@ -121,6 +121,12 @@ int orc_enumerate(int kind, int Q, int T, const float* D, const int* PQ, const i
                   const float* S, const orc_gap* gap, const unsigned char* flags,
                   int number_suboptimal, float delta_ratio, unsigned user_limit, orc_set* as);
 
+/* KSConstrainedNearOptimal (kscw.h:109-351): per branch node only the k_limit best operations continue (std::sort /
+ * std::partial_sort on the operation scores), limits halve down the tree.  Parity unpinned (the header does not build on LP64). */
+int orc_enumerate_ks(int Q, int T, const float* D, const int* PQ, const int* PT, const float* S, const orc_gap* gap,
+                     const unsigned char* flags, int number_suboptimal, float delta_ratio, unsigned k_limit, unsigned user_limit,
+                     orc_set* as);
+
 /* SequenceGaps (gstrings.h:84-164, gstrings.cpp:17-29): template line and one query line
  * per alignment.  Every line is orc_gapped_len() chars (+NUL); qlines is n x stride, stride > that. */
 int orc_gapped_len(const orc_set* as, int T);

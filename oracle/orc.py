@@ -213,6 +213,19 @@ def enumerate_noa(kind, D, PQ, PT, S, gap, flags, number_suboptimal, delta_ratio
                                C.c_float(float(np.float32(delta_ratio))), C.c_uint(user_limit), aset.h)
 
 
+def enumerate_ks(D, PQ, PT, S, gap, flags, number_suboptimal, delta_ratio, k_limit, aset, user_limit=100000):
+    """KSConstrainedNearOptimal (kscw.h:109-351); NOaliParams defaults k_limit 16, user_limit 100000 (noalib.cpp:17-20)."""
+    Q, T = D.shape
+    fl = np.ascontiguousarray(flags if flags is not None else np.ones(T), dtype=np.uint8)
+    D = np.ascontiguousarray(D, dtype=np.float32)
+    PQ = np.ascontiguousarray(PQ, dtype=np.int32)
+    PT = np.ascontiguousarray(PT, dtype=np.int32)
+    S = np.ascontiguousarray(S, dtype=np.float32)
+    return lib().orc_enumerate_ks(Q, T, _fp(D), _ip(PQ), _ip(PT), _fp(S), gap.ref, fl.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                  int(number_suboptimal), C.c_float(float(np.float32(delta_ratio))), C.c_uint(k_limit),
+                                  C.c_uint(user_limit), aset.h)
+
+
 def annot(score, identity, significance=9999.0):
     """FASTA annotation of fastaio.h:79-91 (ostream default precision == %g)."""
     def g(x):

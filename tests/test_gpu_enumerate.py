@@ -154,3 +154,41 @@ def test_batched_enumeration_overflow_is_per_pair(blosum62):
     for k, g in enumerate(one):
         assert np.array_equal(lists[0, k, :lengths[0, k]], g["pairs"])
     b.close()
+
+
+def test_kscw_vs_oracle(blosum62):
+    """KSConstrainedNearOptimal (kscw.h:109-351) on the device: per-node candidate collection, libstdc++-ordered sort /
+    partial_sort of the operations, halving limits, forced optimal paths — against the oracle's restatement (which sorts with
+    the host's std::sort / std::partial_sort).  Parity UNPINNED against the reference (its header does not build on LP64)."""
+    alpha, table = blosum62
+    rng = np.random.RandomState(29)
+    lens = [9, 24, 57, 64, 90, 130, 200]
+    pairs = [homolog_pair(65000 + n, ln, sub_rate=0.2, indel=3) for n, ln in enumerate(lens)]
+    for mode, (gi, ge) in ((1, (11, 1)), (4, (4.73, 0.34)), (3, (11, 1))):
+        b = aln_amd.Batch(gpu_util.ctx(), [p[0] for p in pairs], [p[1] for p in pairs])
+        b.dp_submatrix(alpha, table, mode, gi, ge)
+        for p, (q, t) in enumerate(pairs):
+            T = len(t) + 2
+            flags = orc.make_subopt_regions(T, int(rng.randint(2, 9)))
+            delta = float(rng.choice([0.05, 0.1, 0.3]))
+            nsub = int(rng.choice([5, 40, 300]))
+            klim = int(rng.choice([1, 2, 3, 4, 8, 16, 33]))
+            ulim = int(rng.choice([100000, 7]))
+            S = orc.sim_submatrix(q, t, alpha, table)
+            gap = orc.Gap(mode, gi, ge)
+            rc, D0, PQ0, PT0 = orc.dp_build(S, gap)
+            rc2, sc, pl = orc.optimal(D0, PQ0, PT0, mode == 3)
+            s = orc.AliSet()
+            s.push(pl, sc)
+            if p == len(pairs) - 1:
+                delta, klim, ulim, nsub = 0.6, (33 if mode == 1 else 5), 100000, 300      # hundreds of operations per node: the
+            assert orc.enumerate_ks(D0, PQ0, PT0, S, gap, flags, nsub, delta, klim, s, user_limit=ulim) == 0   # partition / heap paths
+            s.identity(q, t)
+            got = b.enumerate(p, "kscw", nsub, delta, flags, user_limit=ulim, k_limit=klim, max_alignments=max(nsub, len(s)) + 2)
+            assert len(got) == len(s), (mode, gi, p, klim, len(got), len(s))
+            for k, g in enumerate(got):
+                r = s.get(k)
+                assert np.float32(g["score"]).view(np.uint32) == r["score"].view(np.uint32), (mode, gi, p, klim, k)
+                assert g["uid"] == r["uid"], (mode, gi, p, klim, k, g["uid"], r["uid"])
+                assert np.array_equal(g["pairs"], r["pairs"]), (mode, gi, p, klim, k)
+        b.close()
