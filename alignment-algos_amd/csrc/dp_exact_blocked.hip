@@ -512,7 +512,7 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
                                                                  const float* __restrict__ tgi, const float* __restrict__ tge,
                                                                  float* __restrict__ Hbase, uint32_t* __restrict__ Pbase,
                                                                  const float* __restrict__ Sbase, PairResult* __restrict__ res, int rev,
-                                                                 float* __restrict__ scratch_base, int dbg) {
+                                                                 float* __restrict__ scratch_base) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float2* tg = reinterpret_cast<float2*>(lds);          // (tgi, tge) in frame order, PT entries
   float* rowloc0 = lds + 2 * PT;                         // rows a-1 / a of the current tile, index k - kbase
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
             float fn = (float)(a0 + HW * h - 2);       // n of (row a0 + 8h, k = 0)
 #pragma unroll
             for (int i = 0; i < HW; ++i) { W[i] = gi + ge * (fn + (float)i); cm[i] = ninf; m[i] = ninf; ee[i] = ninf; cc[i] = 0; }
-            for (int kc = 0; kc <= ((dbg & 2) ? -1 : a0 - 2); kc += kBR) {
+            for (int kc = 0; kc <= a0 - 2; kc += kBR) {
               float x[kBR];
 #pragma unroll
               for (int u = 0; u < kBR; ++u) {
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
           const float* sbase = rowsF + (size_t)((a0 - 1) & (kTRing - 1)) * PT;
           // 4 source columns x 16 rows per trip: 18 scalar loads, one wait, 148 VALU instructions.  (Double-buffering the
           // SGPRs was tried: under the kernel's SGPR pressure the compiler copies the in-flight registers and waits early.)
-          for (int kc = 0; kc < ((dbg & 1) ? 0 : kbase); kc += kBC) {
+          for (int kc = 0; kc < kbase; kc += kBC) {
 #pragma unroll 1
             for (int k = kc; k < kc + kBC; k += 4) {
               f4v src[kBR];
@@ -707,10 +707,8 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
               if (cb >= 1) { s.m[0] = aload(&fdm[r * PT + bb]); s.e[0] = aload(&fde[r * PT + bb]); s.cidx[0] = aloadi(&fdc[r * PT + bb]); }
               else { s.m[0] = ninf; s.e[0] = ninf; s.cidx[0] = 0; }
               const int tail = kbase + 64 * wave;
-              if (!(dbg & 4)) {
-                scan_range<0, 1, TPOS, false>(s, prev, tg, kbase, tail, gi_c, ge_c);
-                scan_range<0, 1, TPOS, true>(s, prev, tg, tail, tail + 64, gi_c, ge_c);
-              }
+              scan_range<0, 1, TPOS, false>(s, prev, tg, kbase, tail, gi_c, ge_c);
+              scan_range<0, 1, TPOS, true>(s, prev, tg, tail, tail + 64, gi_c, ge_c);
               const float dm = s.m[0], de = s.e[0]; const int dc = s.cidx[0];
               // ---- insertions ---------------------------------------------------------------------------------------
               const size_t colb = (size_t)f.rt(bb - 1);
@@ -741,7 +739,6 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
               const float si = (snear > sfar) ? snear : sfar;
               if (si > opt) { opt = si; cat = (snear > sfar) ? 3 : 2; }
               int oa = a - 1, ob = bb - 1;
-              if (dbg & 8) cat = 0;
               if (cat == 1) {
                 const bool amb = clip0(de + sim, LOCAL) == opt;
                 int k = amb ? 1 : (dc > 1 ? dc : 1);
@@ -902,11 +899,10 @@ int launch_dp_exact_blocked(aln_batch* b) {
   if (tiled) {
     const size_t lds = ((size_t)2 * ptt + 2 * kTLoc) * sizeof(float);
     const int rev = (int)(b->direction == ALN_REV);
-    const int dbg = getenv("ALN_TILED_DEBUG_SKIP") ? atoi(getenv("ALN_TILED_DEBUG_SKIP")) : 0;   // timing experiments only: results are wrong
 #define ALN_TLAUNCH(PTC, TP, LC)                                                                                                 \
     hipLaunchKernelGGL((dp_exact_tiled_kernel<PTC, TP, LC>), dim3(b->n_pairs), dim3(kTW), lds, ctx->stream, b->d_pairs, proto,     \
                        sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr,                        \
-                       tpos ? b->d_tge : nullptr, b->d_H, b->d_P, sub ? nullptr : b->d_S, b->d_res, rev, b->d_xscratch, dbg)
+                       tpos ? b->d_tge : nullptr, b->d_H, b->d_P, sub ? nullptr : b->d_S, b->d_res, rev, b->d_xscratch)
 #define ALN_TLAUNCH_P(PTC)                                                                                                       \
     do { if (tpos) { if (b->islocal) ALN_TLAUNCH(PTC, true, true); else ALN_TLAUNCH(PTC, true, false); }                         \
          else { if (b->islocal) ALN_TLAUNCH(PTC, false, true); else ALN_TLAUNCH(PTC, false, false); } } while (0)
