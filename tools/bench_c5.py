@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
-"""BASELINE config 5 on ONE GPU (the driver's multi-GPU runs shard query rows): n x n synthetic proteins, length
-U[400,600] (seed 5000+s), local 11/1 BLOSUM62, scores only.  Prints GCUPS = sum |q||t| / wall seconds of
-aln_score_all_vs_all (upload of the residues and download of the score block included)."""
+"""BASELINE config 5: n x n synthetic proteins, length U[400,600] (seed 5000+s), local 11/1 BLOSUM62, scores only.
+
+One process per GPU (`python -m torch.distributed.run --nproc-per-node N tools/bench_c5.py n`): rank r owns the block of query
+rows aln_amd.shard.owned_range gives it, every rank holds all templates (2 MB), and the only collective is one all-gather of
+the fp32 score blocks (RCCL; 8 MiB per rank at n = 4096).  Without a launcher it runs the first `rows` query rows on one GPU.
+Prints GCUPS = sum |q||t| / wall seconds of aln_score_all_vs_all (+ the gather), upload of the residues and download of the
+score block included.   usage: bench_c5.py [n] [rows]"""
 import os
 import sys
 import time
@@ -10,14 +14,29 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "alignment-algos_amd"))
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import aln_amd  # noqa: E402
+from aln_amd.shard import owned_range  # noqa: E402
 from aln_amd.synth import MT19937, residues  # noqa: E402
 
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    rank, world, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
     rows = int(sys.argv[2]) if len(sys.argv) > 2 else n
+    rehearse = os.environ.get("ALN_BENCH_REHEARSE_ON_ONE_GPU") == "1"      # every rank on device 0, gloo: control flow only
+    dist = dev = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearse:
+            local_rank = 0
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dev = torch.device("cpu")
+        else:
+            torch.cuda.set_device(local_rank)
+            dev = torch.device("cuda", local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     lines = open(os.path.join(ROOT, "tests", "golden", "BLOSUM62")).read().split("\n")
     k = 0
     while lines[k].startswith("#"):
@@ -30,15 +49,33 @@ def main():
         ln = 400 + int(g.draw(1)[0] % 201)
         seqs.append(residues(g, ln))
     pool = aln_amd.SeqPool(seqs)
-    ctx = aln_amd.Context(0)
-    aln_amd.score_all_vs_all(ctx, pool, pool, alphabet, table, 11, 1, 0, min(64, rows))   # warm-up
+    ctx = aln_amd.Context(local_rank)
+    lo, hi = owned_range(rows, world, rank)
+    aln_amd.score_all_vs_all(ctx, pool, pool, alphabet, table, 11, 1, lo, min(lo + 64, hi))   # warm-up
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
-    sc = aln_amd.score_all_vs_all(ctx, pool, pool, alphabet, table, 11, 1, 0, rows)
+    sc = aln_amd.score_all_vs_all(ctx, pool, pool, alphabet, table, 11, 1, lo, hi)
+    full = sc
+    if world > 1:
+        import torch
+        mx = max(owned_range(rows, world, r)[1] - owned_range(rows, world, r)[0] for r in range(world))
+        buf = torch.zeros((mx, n), dtype=torch.float32, device=dev)
+        buf[:hi - lo] = torch.from_numpy(sc).to(dev)
+        out = torch.empty((world * mx, n), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(out, buf)                       # the one collective of the path
+        out = out.cpu().numpy().reshape(world, mx, n)
+        full = np.concatenate([out[r, :owned_range(rows, world, r)[1] - owned_range(rows, world, r)[0]] for r in range(world)])
+        dist.barrier()
     dt = time.perf_counter() - t0
-    lens = np.array([len(s) for s in seqs], dtype=np.float64)
-    cells = lens[:rows].sum() * lens.sum()
-    print("config5 %d x %d: %.3f s, %.1f GCUPS, checksum %.0f, self-scores ok=%s" % (
-        rows, n, dt, cells / dt / 1e9, float(sc.sum()), bool((np.diag(sc[:, :rows]) >= sc[:, :rows].max(axis=1) - 1e-6).all())))
+    if rank == 0:
+        lens = np.array([len(s) for s in seqs], dtype=np.float64)
+        cells = lens[:rows].sum() * lens.sum()
+        print("config5 %d x %d on %d rank(s)%s: %.3f s, %.1f GCUPS, checksum %.0f, self-scores ok=%s" % (
+            rows, n, world, " [one-GPU rehearsal]" if rehearse else "", dt, cells / dt / 1e9, float(full.sum()),
+            bool((np.diag(full[:, :rows]) >= full[:, :rows].max(axis=1) - 1e-6).all())))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
