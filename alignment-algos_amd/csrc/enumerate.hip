@@ -49,9 +49,14 @@ __global__ __launch_bounds__(64) void enumerate_kernel(const PairDesc* __restric
   uint32_t n_as = (uint32_t)a.first_slot + 1;   // as.push_back(SingleAlignment())  cw.h:82 / ucw.h:78
   uint32_t n_nodes = 0;
   int status = 0;
-  auto sync_mem = [&]() { __builtin_amdgcn_s_waitcnt(0); };   // vmcnt(0): lane 0's stores are in L2 before anyone reads them
+  // Lane 0 writes the pools, every lane reads them back through L2.  A store is only waited for (one memory round trip) right
+  // before the next cross-lane read: `dirty` marks stores in flight, flush() is the s_waitcnt.  (Lane 0 re-reading a word it
+  // wrote itself needs no wait: same lane, same address, program order.)
+  bool dirty = false;
+  auto flush = [&]() { if (dirty) { __builtin_amdgcn_s_waitcnt(0); dirty = false; } };
   if (lane == 0) { st_u(&a.head[a.first_slot], kNoNode); st_f(&a.score[a.first_slot], 0.f); }
-  sync_mem();
+  dirty = true;
+  flush();
 
   const float top = HV(Q - 1, T - 1);
   float thr = (1.f - a.delta_ratio) * top;       // cw.h:86-88
@@ -65,12 +70,13 @@ __global__ __launch_bounds__(64) void enumerate_kernel(const PairDesc* __restric
       st_u(&a.head[k], n_nodes);
     }
     ++n_nodes;
-    sync_mem();
+    dirty = true;
   };
-  auto set_score = [&](int k, float s) { if (lane == 0) st_f(&a.score[k], s); sync_mem(); };
+  auto set_score = [&](int k, float s) { if (lane == 0) st_f(&a.score[k], s); dirty = true; };
   auto base_case = [&](int q0, int t0, int k0) {   // cw.h:100-108 / ucw.h:93-101
     prepend(k0, q0, t0);
     prepend(k0, 0, 0);
+    flush();
     float s = ld_f(&a.score[k0]);
     s += HV(q0, t0);
     set_score(k0, s);
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(64) void enumerate_kernel(const PairDesc* __restric
       } else { q0 -= n_proc; t0 -= n_proc; }
     }
     if (lane == 0) { st_u(&a.head[k0], hd); st_f(&a.score[k0], sc); }
-    sync_mem();
+    dirty = true;
   };
 
   // Depth-first search with an explicit stack of branch frames.  A pending call is either
@@ -128,6 +134,7 @@ __global__ __launch_bounds__(64) void enumerate_kernel(const PairDesc* __restric
   long guard = 0;
   while ((call != CALL_NONE || sp > 0) && status == 0) {
     if (++guard > (1L << 40)) { status = ALN_E_OVERFLOW; break; }
+    flush();
     if (call == CALL_OPT) {
       call = CALL_NONE;
       int q0 = cq, t0 = ct; const int k0 = ck; const bool force = cforce;
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(64) void enumerate_kernel(const PairDesc* __restric
         st_u(f + 0, (uint32_t)q0); st_u(f + 1, (uint32_t)t0); st_u(f + 2, (uint32_t)k0); st_u(f + 3, 0u);
         st_u(f + 4, ch); st_u(f + 5, __float_as_uint(cs)); st_u(f + 6, __float_as_uint(r));
       }
-      sync_mem();
+      dirty = true;
       ++sp;
       continue;
     }
@@ -165,41 +172,95 @@ __global__ __launch_bounds__(64) void enumerate_kernel(const PairDesc* __restric
     const int ndel = t0 - 2, nins = q0 - 2;
     const int ncand = 1 + ndel + nins;
     int found = -1; float fg = 0.f; int fq = 0, ft = 0;
-    // 4 x 64 candidates per trip: the score loads of all four groups are in flight together, the ballots keep the order
-    for (int base = cursor; base < ncand && found < 0; base += 256) {
-      bool ok[4]; float g[4]; int pq[4], pt[4];
+    if (e.model == ALN_GAP_AFFINE_CONST) {
+      // Constant affine gaps: the candidate's cell and its gap cost are pure arithmetic, so the scan is written without a single
+      // branch around a load — 16 x 64 score loads are in flight per trip and one HBM round trip (~2 us) covers 1024 candidates.
+      // (With loads inside the if/else ladder below the compiler has to wait for each one before the next group.)
+      constexpr int kTrip = 16;
+      const bool fdel = (e.align_type == ALN_LOCAL || e.align_type == ALN_SEMI_LOCAL || e.align_type == ALN_LOCAL_GLOBAL);
+      const bool fins = (e.align_type == ALN_LOCAL || e.align_type == ALN_SEMI_LOCAL || e.align_type == ALN_GLOBAL_LOCAL);
+      const uint16_t* H16p = reinterpret_cast<const uint16_t*>(Hbase) + pd.plane_off;
+      const float* H32p = Hbase + pd.plane_off;
+      for (int base = cursor; base < ncand && found < 0; base += 64 * kTrip) {
+        int cq[kTrip], ct[kTrip]; float fsc[kTrip];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = base + 64 * u + lane;
-        ok[u] = false; g[u] = 0.f; pq[u] = 0; pt[u] = 0;
-        if (idx < ncand) {
-          if (idx == 0) {                                     // match, cw.h:151-162
-            pq[u] = q0 - 1; pt[u] = t0 - 1;
-            const float fsc = HV(pq[u], pt[u]);
-            ok[u] = fsc + r > thr;
-          } else if (idx <= ndel) {                           // deletions i = t0-2 .. 1, cw.h:166-178
-            pq[u] = q0 - 1; pt[u] = t0 - 1 - idx;
-            const float fsc = HV(pq[u], pt[u]);
-            g[u] = dev_deletion(e, pt[u], t0);
-            ok[u] = fsc + r - g[u] > thr;
-          } else {                                            // insertions j = q0-2 .. 1, cw.h:182-194
-            pq[u] = q0 - 2 - (idx - ndel - 1); pt[u] = t0 - 1;
-            const float fsc = HV(pq[u], pt[u]);
-            g[u] = dev_insertion(e, pq[u], q0, pt[u], t0);
-            ok[u] = fsc + r - g[u] > thr;
+        for (int u = 0; u < kTrip; ++u) {
+          const int idx = base + 64 * u + lane;
+          const bool isdel = idx <= ndel;                       // idx 0 (match) has the same row
+          int q = isdel ? q0 - 1 : q0 - 2 - (idx - ndel - 1);
+          int t = idx == 0 ? t0 - 1 : isdel ? t0 - 1 - idx : t0 - 1;
+          const bool in = idx < ncand;
+          q = in ? q : q0 - 1; t = in ? t : t0 - 1;            // lanes past the end read a harmless cell
+          cq[u] = q; ct[u] = t;
+        }
+        if (a.h_mode == 0) {
+#pragma unroll
+          for (int u = 0; u < kTrip; ++u) fsc[u] = H32p[(size_t)cq[u] * ld + ct[u]];
+        } else {
+#pragma unroll
+          for (int u = 0; u < kTrip; ++u) fsc[u] = (float)H16p[(size_t)cq[u] * ld + ct[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < kTrip; ++u) {
+          if (found >= 0 || base + 64 * u >= ncand) break;
+          const int idx = base + 64 * u + lane;
+          const int q = cq[u], t = ct[u];
+          float g = 0.f;
+          if (idx != 0) {
+            if (idx <= ndel) {                                  // aasubalib.h:27-51
+              const int len = t0 - t - 1;
+              g = (len < 1 || (fdel && (t == 0 || t0 == T - 1))) ? 0.f : e.gi + e.ge * (float)(len - 1);
+            } else {                                            // aasubalib.h:53-77
+              const int len = q0 - q - 1;
+              g = (len < 1 || (fins && (q == 0 || q0 == Q - 1))) ? 0.f : e.gi + e.ge * (float)(len - 1);
+            }
+          }
+          const bool ok = idx < ncand && (idx == 0 ? fsc[u] + r > thr : fsc[u] + r - g > thr);
+          const unsigned long long m = __ballot(ok);
+          if (m) {
+            const int l = __builtin_ctzll(m);
+            found = base + 64 * u + l;
+            fg = __shfl(g, l); fq = __shfl(q, l); ft = __shfl(t, l);
           }
         }
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const unsigned long long m = __ballot(ok[u]);
-        if (m && found < 0) {
-          const int l = __builtin_ctzll(m);
-          found = base + 64 * u + l;
-          fg = __shfl(g[u], l); fq = __shfl(pq[u], l); ft = __shfl(pt[u], l);
+    } else {
+    // 4 x 64 candidates per trip: the score loads of all four groups are in flight together, the ballots keep the order
+      for (int base = cursor; base < ncand && found < 0; base += 256) {
+        bool ok[4]; float g[4]; int pq[4], pt[4];
+  #pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = base + 64 * u + lane;
+          ok[u] = false; g[u] = 0.f; pq[u] = 0; pt[u] = 0;
+          if (idx < ncand) {
+            if (idx == 0) {                                     // match, cw.h:151-162
+              pq[u] = q0 - 1; pt[u] = t0 - 1;
+              const float fsc = HV(pq[u], pt[u]);
+              ok[u] = fsc + r > thr;
+            } else if (idx <= ndel) {                           // deletions i = t0-2 .. 1, cw.h:166-178
+              pq[u] = q0 - 1; pt[u] = t0 - 1 - idx;
+              const float fsc = HV(pq[u], pt[u]);
+              g[u] = dev_deletion(e, pt[u], t0);
+              ok[u] = fsc + r - g[u] > thr;
+            } else {                                            // insertions j = q0-2 .. 1, cw.h:182-194
+              pq[u] = q0 - 2 - (idx - ndel - 1); pt[u] = t0 - 1;
+              const float fsc = HV(pq[u], pt[u]);
+              g[u] = dev_insertion(e, pq[u], q0, pt[u], t0);
+              ok[u] = fsc + r - g[u] > thr;
+            }
+          }
+        }
+  #pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned long long m = __ballot(ok[u]);
+          if (m && found < 0) {
+            const int l = __builtin_ctzll(m);
+            found = base + 64 * u + l;
+            fg = __shfl(g[u], l); fq = __shfl(pq[u], l); ft = __shfl(pt[u], l);
+          }
         }
       }
-    }
+  }
     if (found < 0) {
       --sp;                                                 // branch() returns
       if (cursor == 0) {                                    // k == k0: nothing passed, finish along stored pointers
@@ -210,13 +271,13 @@ __global__ __launch_bounds__(64) void enumerate_kernel(const PairDesc* __restric
     if ((uint32_t)k == n_as) {                              // as.push_back(curr)
       if (n_as >= a.ali_cap) { status = ALN_E_OVERFLOW; break; }
       if (lane == 0) { st_u(&a.head[n_as], curr_head); st_f(&a.score[n_as], curr_score); }
-      sync_mem();
+      dirty = true;
       ++n_as;
     }
     prepend(k, q0, t0);
     set_score(k, r - fg);
     if (lane == 0) st_u(f + 3, (uint32_t)(found + 1));
-    sync_mem();
+    dirty = true;
     if (cw) { call = CALL_OPT; cq = fq; ct = ft; ck = k; cforce = false; }      // opt_path(cand,k,false)
     else { call = CALL_BRANCH; cq = fq; ct = ft; ck = k; cforce = false; }      // ucw: branch(cand,k)
   }
