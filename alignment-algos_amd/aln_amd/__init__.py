@@ -64,8 +64,8 @@ EXPORTS = [
     "aln_ctx_create", "aln_ctx_destroy", "aln_error_string", "aln_last_error", "aln_ctx_synchronize", "aln_has_gfx950",
     "aln_batch_create", "aln_batch_destroy", "aln_batch_n_pairs", "aln_batch_device_bytes", "aln_batch_dp",
     "aln_batch_reevaluate", "aln_batch_dp_kernel_name", "aln_batch_dp_sub", "aln_batch_get_cells", "aln_batch_get_sim",
-    "aln_batch_get_corner_scores", "aln_batch_optimal", "aln_batch_optimal_subali", "aln_batch_enumerate", "aln_batch_enumerate_all", "aln_batch_last_enum_ms", "aln_identity",
-    "aln_gapped_length", "aln_gapped_strings", "aln_hmap2_gap_arrays", "aln_score_all_vs_all", "aln_batch_last_dp_ms", "aln_batch_dp_algorithmic_bytes", "aln_batch_cells",
+    "aln_batch_get_corner_scores", "aln_batch_optimal", "aln_batch_optimal_enqueue", "aln_batch_optimal_collect", "aln_batch_optimal_subali", "aln_batch_enumerate", "aln_batch_enumerate_all", "aln_batch_last_enum_ms", "aln_identity",
+    "aln_gapped_length", "aln_gapped_strings", "aln_hmap2_gap_arrays", "aln_score_all_vs_all", "aln_batch_last_dp_ms", "aln_batch_dp_ms_history", "aln_batch_dp_algorithmic_bytes", "aln_batch_cells",
 ]
 
 _LIB = None
@@ -110,6 +110,8 @@ def lib():
         L.aln_batch_get_sim.argtypes = [C.c_void_p, C.c_int32, _fp]
         L.aln_batch_get_corner_scores.argtypes = [C.c_void_p, _fp]
         L.aln_batch_optimal.argtypes = [C.c_void_p, _fp, _ip, _ip, C.c_int32, _ip]
+        L.aln_batch_optimal_enqueue.argtypes = [C.c_void_p]
+        L.aln_batch_optimal_collect.argtypes = [C.c_void_p, _fp, _ip, _ip]
         L.aln_batch_optimal_subali.argtypes = [C.c_void_p, _fp, _ip, _ip, C.c_int32, _ip]
         L.aln_batch_enumerate.argtypes = [C.c_void_p, C.c_int32, C.POINTER(AlnNoa), C.POINTER(C.c_uint8), C.POINTER(AlnAlignment),
                                           C.c_int32, _ip, C.c_int64, _ip]
@@ -121,6 +123,7 @@ def lib():
         L.aln_gapped_strings.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(AlnAlignment), C.c_int32, _ip,
                                          C.c_char_p, C.c_char_p, C.c_int32]
         L.aln_batch_last_dp_ms.argtypes = [C.c_void_p, _fp]
+        L.aln_batch_dp_ms_history.argtypes = [C.c_void_p, _fp, C.c_int32]
         L.aln_score_all_vs_all.argtypes = [C.c_void_p, C.POINTER(AlnSeqs), C.POINTER(AlnSeqs), C.POINTER(AlnSubmatrix), C.POINTER(AlnGap),
                                            C.c_int32, C.c_int32, _fp]
         L.aln_hmap2_gap_arrays.argtypes = [_fp, C.c_int64, C.c_float, C.c_float, C.c_float, _fp, _fp]
@@ -331,6 +334,13 @@ class Batch:
         _check(lib().aln_batch_last_dp_ms(self.h, C.byref(ms)), self.ctx.h)
         return ms.value
 
+    def dp_ms_history(self, n):
+        ms = np.zeros(n, dtype=np.float32)
+        got = lib().aln_batch_dp_ms_history(self.h, _f(ms), n)
+        if got < 0:
+            raise AlnError(E_HIP, "aln_batch_dp_ms_history")
+        return ms[:got]
+
     def cells(self):
         return lib().aln_batch_cells(self.h)
 
@@ -417,6 +427,18 @@ class Batch:
         a, b = C.c_float(0), C.c_float(0)
         _check(lib().aln_batch_last_enum_ms(self.h, C.byref(a), C.byref(b)), self.ctx.h)
         return a.value, b.value
+
+    def optimal_enqueue(self):
+        """Launch find_max + traceback + the copy of the results into a pinned slot; returns at once (two slots)."""
+        _check(lib().aln_batch_optimal_enqueue(self.h), self.ctx.h)
+
+    def optimal_collect(self):
+        """Wait for the oldest enqueued slot -> scores[n], list lengths[n], status[n]."""
+        scores = np.empty(self.n, dtype=np.float32)
+        cnt = np.zeros(self.n, dtype=np.int32)
+        status = np.zeros(self.n, dtype=np.int32)
+        _check(lib().aln_batch_optimal_collect(self.h, _f(scores), _i(cnt), _i(status)), self.ctx.h)
+        return scores, cnt, status
 
     def optimal(self, want_pairs=True, subali=False):
         """-> scores[n], list of pair arrays (list order), status[n]"""

@@ -11,18 +11,21 @@ def owned_range(n_total, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_scores(local_scores, n_total, world, rank, device=None):
+def gather_scores(local_scores, n_total, world, rank, device=None, stream=None):
     """All-gather the per-rank score blocks into the global order.  Blocks may differ by one element: pad to the
-    largest block, gather once, strip the padding."""
+    largest block, gather once, strip the padding.  `stream`: a torch.cuda.Stream to run the (tiny) copies and the collective
+    on, so that waiting for the gathered scores does not wait for compute kernels queued on the main stream."""
     if world == 1:
         return np.asarray(local_scores, dtype=np.float32)
+    import contextlib
     import torch
     import torch.distributed as dist
     sizes = [owned_range(n_total, world, r)[1] - owned_range(n_total, world, r)[0] for r in range(world)]
     mx = max(sizes)
-    buf = torch.zeros(mx, dtype=torch.float32, device=device)
-    buf[:len(local_scores)] = torch.as_tensor(np.asarray(local_scores, dtype=np.float32), device=device)
-    out = torch.empty(mx * world, dtype=torch.float32, device=device)
-    dist.all_gather_into_tensor(out, buf)
-    out = out.cpu().numpy().reshape(world, mx)
+    with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+        buf = torch.zeros(mx, dtype=torch.float32, device=device)
+        buf[:len(local_scores)] = torch.as_tensor(np.asarray(local_scores, dtype=np.float32), device=device)
+        out = torch.empty(mx * world, dtype=torch.float32, device=device)
+        dist.all_gather_into_tensor(out, buf)
+        out = out.cpu().numpy().reshape(world, mx)
     return np.concatenate([out[r, :sizes[r]] for r in range(world)])

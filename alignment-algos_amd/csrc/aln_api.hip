@@ -131,7 +131,6 @@ int aln_batch_create(aln_ctx* ctx, const aln_seqs* queries, const aln_seqs* temp
 #undef TRY
   if (hipMemcpyAsync(b->d_pairs, b->h_pairs.data(), sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
       hipMemsetAsync(b->d_res, 0, sizeof(PairResult) * (n_pairs ? n_pairs : 1), ctx->stream) != hipSuccess ||
-      hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess ||
       hipStreamSynchronize(ctx->stream) != hipSuccess) {
     ctx->last_error = "batch upload failed";
     aln_batch_destroy(b);
@@ -146,8 +145,8 @@ void aln_batch_destroy(aln_batch* b) {
   hipFree(b->d_pairs); hipFree(b->d_qcodes); hipFree(b->d_tcodes); hipFree(b->d_H); hipFree(b->d_P); hipFree(b->d_S);
   hipFree(b->d_res); hipFree(b->d_table32); hipFree(b->d_tablef); hipFree(b->d_tgi); hipFree(b->d_tge);
   hipFree(b->d_path); hipFree(b->d_bounds); hipFree(b->d_xscratch); hipFree(b->d_tcn); hipFree(b->d_deltab); hipFree(b->d_deltab_off); hipFree(b->d_instab);
-  if (b->ev0) hipEventDestroy(b->ev0);
-  if (b->ev1) hipEventDestroy(b->ev1);
+  for (int k = 0; k < 2; ++k) { if (b->h_slot[k]) hipHostFree(b->h_slot[k]); if (b->slot_ev[k]) hipEventDestroy(b->slot_ev[k]); }
+  for (int k = 0; k < aln_batch::kEvRing; ++k) { if (b->ring0[k]) hipEventDestroy(b->ring0[k]); if (b->ring1[k]) hipEventDestroy(b->ring1[k]); }
   delete b;
 }
 
@@ -298,6 +297,12 @@ int run_dp(aln_batch* b, bool simplane_integral) {
   if (b->algo == ALN_DP_FAST && !fast) return ALN_E_NOT_INTEGRAL;
   b->ptr_mode = tagged ? 1 : 0;
   b->h_mode = (tagged && b->islocal && !getenv("ALN_NO_H16")) ? 1 : 0;   // local scores of the tagged path are integers in [0, 65535]
+  {
+    const int slot = (int)(b->n_builds % aln_batch::kEvRing);
+    if (!b->ring0[slot]) { ALN_HIP_CHECK(ctx, hipEventCreate(&b->ring0[slot])); ALN_HIP_CHECK(ctx, hipEventCreate(&b->ring1[slot])); }
+    b->ev0 = b->ring0[slot]; b->ev1 = b->ring1[slot];
+    ++b->n_builds;
+  }
   ALN_HIP_CHECK(ctx, hipEventRecord(b->ev0, ctx->stream));
   int rc = tagged ? launch_dp_affine_tag(b) : fast ? launch_dp_affine_int(b, !sub) : launch_dp_exact(b);
   if (rc) return rc;
@@ -397,6 +402,18 @@ int aln_batch_last_dp_ms(aln_batch* b, float* ms) {
   ALN_HIP_CHECK(b->ctx, hipEventSynchronize(b->ev1));
   ALN_HIP_CHECK(b->ctx, hipEventElapsedTime(ms, b->ev0, b->ev1));
   return ALN_OK;
+}
+
+int aln_batch_dp_ms_history(aln_batch* b, float* ms, int32_t max_n) {
+  if (!b || !ms || max_n < 0) return -1;
+  long avail = b->n_builds < aln_batch::kEvRing ? b->n_builds : aln_batch::kEvRing;
+  int n = (int)(avail < max_n ? avail : max_n);
+  if (b->n_pairs == 0) { for (int k = 0; k < n; ++k) ms[k] = 0.f; return n; }
+  for (int k = 0; k < n; ++k) {                       // ms[0] = the latest build, ms[1] the one before ...
+    const int slot = (int)((b->n_builds - 1 - k) % aln_batch::kEvRing);
+    if (hipEventSynchronize(b->ring1[slot]) != hipSuccess || hipEventElapsedTime(&ms[k], b->ring0[slot], b->ring1[slot]) != hipSuccess) return -1;
+  }
+  return n;
 }
 
 int aln_batch_get_cells(aln_batch* b, int32_t pair, float* score, int32_t* prev_q, int32_t* prev_t) {
@@ -512,6 +529,45 @@ int aln_batch_optimal(aln_batch* b, float* scores, int32_t* n, int32_t* pairs, i
   int rc = launch_traceback(b, false);
   if (rc) return rc;
   return fetch_paths(b, scores, n, pairs, pair_stride, status, !b->islocal, b->direction == ALN_FWD);
+}
+
+int aln_batch_optimal_enqueue(aln_batch* b) {
+  if (!b) return ALN_E_ARG;
+  if (!b->have_dp || b->have_sub) return ALN_E_STATE;
+  if (b->slot_count == 2) return ALN_E_STATE;
+  aln_ctx* ctx = b->ctx;
+  const int s = (b->slot_head + b->slot_count) & 1;
+  if (b->n_pairs > 0) {
+    if (!b->h_slot[s]) {
+      ALN_HIP_CHECK(ctx, hipHostMalloc((void**)&b->h_slot[s], sizeof(PairResult) * b->n_pairs));
+      ALN_HIP_CHECK(ctx, hipEventCreateWithFlags(&b->slot_ev[s], hipEventDisableTiming));
+    }
+    int rc = launch_traceback(b, false);
+    if (rc) return rc;
+    ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->h_slot[s], b->d_res, sizeof(PairResult) * b->n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+    ALN_HIP_CHECK(ctx, hipEventRecord(b->slot_ev[s], ctx->stream));
+  }
+  b->slot_local[s] = b->islocal;
+  ++b->slot_count;
+  return ALN_OK;
+}
+
+int aln_batch_optimal_collect(aln_batch* b, float* scores, int32_t* n, int32_t* status) {
+  if (!b) return ALN_E_ARG;
+  if (b->slot_count == 0) return ALN_E_STATE;
+  const int s = b->slot_head;
+  if (b->n_pairs > 0) {
+    ALN_HIP_CHECK(b->ctx, hipEventSynchronize(b->slot_ev[s]));
+    const PairResult* r = b->h_slot[s];
+    for (int p = 0; p < b->n_pairs; ++p) {
+      if (scores) scores[p] = b->slot_local[s] ? r[p].best : r[p].corner;
+      if (n) n[p] = r[p].n_path;
+      if (status) status[p] = r[p].status;
+    }
+  }
+  b->slot_head ^= 1;
+  --b->slot_count;
+  return ALN_OK;
 }
 
 int aln_batch_optimal_subali(aln_batch* b, float* scores, int32_t* n, int32_t* pairs, int32_t pair_stride, int32_t* status) {

@@ -90,8 +90,16 @@ struct aln_batch {
   int32_t ptr_mode;                            // encoding of the P plane words (aln_device.h decode_ptr)
   int32_t h_mode;                              // score plane element type: 0 fp32, 1 uint16 (aln_device.h load_score)
   std::string kernel_name;
-  hipEvent_t ev0, ev1;
+  hipEvent_t ev0, ev1;                          // around the DP kernel(s) of the latest build
+  static const int kEvRing = 64;               // ... and of the builds before it (aln_batch_dp_ms_history)
+  hipEvent_t ring0[kEvRing] = {}, ring1[kEvRing] = {};
+  long n_builds = 0;
   float enum_search_ms = 0.f, enum_unroll_ms = 0.f;   // last aln_batch_enumerate_all
+  // aln_batch_optimal_enqueue / _collect: two pinned result slots
+  aln::PairResult* h_slot[2] = {nullptr, nullptr};
+  hipEvent_t slot_ev[2] = {nullptr, nullptr};
+  bool slot_local[2] = {false, false};
+  int slot_head = 0, slot_count = 0;
   std::vector<int32_t> h_bounds;
   // retained similarity description for reevaluate()
   std::vector<float> h_table; int32_t alpha_n; std::string alphabet;

@@ -132,12 +132,31 @@ def main():
 
     from aln_amd.shard import gather_scores
 
+    # A step = DPMatrix::reevaluate (DP + corner kernels) + Optimal (find_max + traceback kernels, per-pair results copied to the
+    # host) [+ the gather of the scores over the ranks].  Steps are software-pipelined: step k's kernels and result copy are
+    # enqueued, then step k-1's results are collected (and gathered), so the host's launch / copy latency hides behind the
+    # kernels of the next step.  Every enqueued step is collected inside the timed region.
+    pending = [0]
+    side = torch.cuda.Stream(dev) if (world > 1 and not rehearse) else None    # the score gather does not queue behind the kernels
+
+    def collect():
+        sc, cnt, status = batch.optimal_collect()
+        pending[0] -= 1
+        if world > 1:                                       # the one collective of the path: all ranks' scores (RCCL)
+            gather_scores(sc, args.pairs * world, world, rank, device=None if rehearse else dev, stream=side)
+        return sc, status
+
     def step():
         batch.reevaluate()
-        sc, _, status = batch.optimal(want_pairs=False)     # find_max + traceback on the device; scores to host
-        if world > 1:                                       # the one collective of the path: all ranks' scores (RCCL)
-            gather_scores(sc, args.pairs * world, world, rank, device=None if rehearse else dev)
-        return sc, status
+        batch.optimal_enqueue()
+        pending[0] += 1
+        return collect() if pending[0] == 2 else (None, None)
+
+    def drain():
+        out = (None, None)
+        while pending[0]:
+            out = collect()
+        return out
 
     def fence():
         if world > 1:
@@ -146,14 +165,15 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    kernel_ms = []
+    drain()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sc, status = step()
-        kernel_ms.append(batch.last_dp_ms())
+        step()
+    sc, status = drain()
     fence()
     elapsed = time.perf_counter() - t0
+    kernel_ms = batch.dp_ms_history(min(args.steps, 64))     # HIP events around the DP kernel of each timed step (ctx stream)
     assert (status == 0).all()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)

@@ -211,6 +211,12 @@ int aln_batch_get_corner_scores(aln_batch* b, float* scores);
  * order; n[p] = list length; status[p] = 0 or ALN_E_STARTPAIR.  scores/n/status/pairs may be NULL. */
 int aln_batch_optimal(aln_batch* b, float* scores, int32_t* n, int32_t* pairs, int32_t pair_stride,
                       int32_t* status);
+/* The same, split so that a caller can keep the device busy: _enqueue launches find_max + traceback and the copy of the
+ * per-pair results into a pinned host slot (two slots; ALN_E_STATE when both are waiting) and returns at once; _collect waits
+ * for the OLDEST enqueued slot and hands out its scores / list lengths / status.  A loop `reevaluate; enqueue; collect(previous)`
+ * overlaps the host's launch and copy latency of one step with the kernels of the next (bench.py). */
+int aln_batch_optimal_enqueue(aln_batch* b);
+int aln_batch_optimal_collect(aln_batch* b, float* scores, int32_t* n, int32_t* status);
 /* Optimal_Subali::enumerate (optimal_subali.h:60-84) on the rectangles of the last aln_batch_dp_sub. */
 int aln_batch_optimal_subali(aln_batch* b, float* scores, int32_t* n, int32_t* pairs,
                              int32_t pair_stride, int32_t* status);
@@ -272,6 +278,9 @@ int aln_hmap2_gap_arrays(const float* t_sse, int64_t n, float gap_init, float ga
 /* Milliseconds the device spent in the DP kernel(s) of the last aln_batch_dp, from HIP events recorded on
  * the ctx stream around those launches; synchronises the stream. */
 int aln_batch_last_dp_ms(aln_batch* b, float* ms);
+/* The same for up to max_n of the latest builds (ms[0] = the latest; the library keeps 64 event pairs), so that a pipelined
+ * caller can read the kernel times after its loop instead of synchronising inside it.  Returns how many it wrote, -1 on error. */
+int aln_batch_dp_ms_history(aln_batch* b, float* ms, int32_t max_n);
 /* algorithmic bytes per DP launch: 8 B per cell (fp32 score + packed pointer), SURVEY.md §8(d) */
 int64_t aln_batch_dp_algorithmic_bytes(const aln_batch* b);
 int64_t aln_batch_cells(const aln_batch* b);      /* sum over pairs of |q|*|t| = (Q-2)(T-2) */

@@ -591,3 +591,29 @@ def test_batched_subrectangle_fills(blosum62):
                     if rc2 == 0:
                         assert np.float32(scores[k]).view(np.uint32) == sc.view(np.uint32) and np.array_equal(lists[k], pairs)
             b.close()
+
+
+def test_optimal_enqueue_collect(blosum62):
+    """aln_batch_optimal_enqueue / _collect (what bench.py pipelines) give the scores, list lengths and status of
+    aln_batch_optimal; two slots, FIFO, a third enqueue is a state error; aln_batch_dp_ms_history reports every build."""
+    alpha, table = blosum62
+    pairs = [homolog_pair(99000 + n, ln) for n, ln in enumerate((30, 200, 513))] + [("", "ACD")]
+    for mode in (3, 1):
+        b = aln_amd.Batch(gpu_util.ctx(), [p[0] for p in pairs], [p[1] for p in pairs])
+        b.dp_submatrix(alpha, table, mode, 11, 1)
+        sc0, lists0, st0 = b.optimal()
+        b.optimal_enqueue()
+        b.reevaluate()
+        b.optimal_enqueue()
+        with pytest.raises(aln_amd.AlnError) as ei:
+            b.optimal_enqueue()
+        assert ei.value.code == aln_amd.E_STATE
+        for _ in range(2):
+            sc, cnt, st = b.optimal_collect()
+            assert np.array_equal(sc.view(np.uint32), sc0.view(np.uint32)) and np.array_equal(st, st0)
+            assert cnt.tolist() == [len(x) for x in lists0]
+        with pytest.raises(aln_amd.AlnError):
+            b.optimal_collect()
+        ms = b.dp_ms_history(8)
+        assert len(ms) == 2 and (ms > 0).all()
+        b.close()
