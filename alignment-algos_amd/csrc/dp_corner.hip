@@ -4,7 +4,7 @@
 // column with the evaluator's end-gap rules), :844-874 / :995-1028 (reverse: cell (q0,t0)), the two
 // degenerate shortcuts :375-390 / :558-573 / :713-728 / :899-914, and the seed rule of
 // Optimal::find_max (optimal.h:108-124) / Optimal_Rev::find_max (optimal_rev.h:117-131).
-// One wave per pair; O(Q+T) reads of the finished score plane, literal fp32 arithmetic
+// Four waves per pair (the loop is one dependent memory round trip per 256 candidates); O(Q+T) reads of the finished score plane, literal fp32 arithmetic
 // (s = D; s -= g; s += S; clip), so it serves the integer fast path and the exact path alike.
 // Candidate order = match, deletions k ascending (in the build frame), insertions k ascending;
 // "replace on strict >" == the first candidate reaching the maximum.
@@ -12,7 +12,9 @@
 
 namespace aln {
 
-__global__ __launch_bounds__(64) void dp_corner_kernel(const PairDesc* __restrict__ pairs, EvalDev proto,
+constexpr int kCornerThreads = 256;
+
+__global__ __launch_bounds__(kCornerThreads) void dp_corner_kernel(const PairDesc* __restrict__ pairs, EvalDev proto,
                                                        const uint8_t* __restrict__ qcodes, const uint8_t* __restrict__ tcodes,
                                                        const float* __restrict__ tgi, const float* __restrict__ tge,
                                                        float* __restrict__ Hbase, uint32_t* __restrict__ Pbase,
@@ -28,7 +30,9 @@ __global__ __launch_bounds__(64) void dp_corner_kernel(const PairDesc* __restric
   bind_table_model(e, proto, pd);
   e.S = Sbase ? Sbase + pd.plane_off : nullptr;
   auto HV = [&](int i, int j) -> float { return load_score(Hbase, pd.plane_off, pd.ld, i, j, h_mode); };
-  const int ld = pd.ld, lane = threadIdx.x;
+  __shared__ float red_s[kCornerThreads / 64];
+  __shared__ int red_i[kCornerThreads / 64], red_h[kCornerThreads / 64];
+  const int ld = pd.ld, lane = threadIdx.x;          // "lane" = thread of the pair's workgroup; thread 0 writes the results
   const Frame f = {pd.q0, pd.q1, pd.t0, pd.t1, rev};
   const int nQ = f.nQ(), nT = f.nT();
   const bool local = islocal != 0;
@@ -53,7 +57,7 @@ __global__ __launch_bounds__(64) void dp_corner_kernel(const PairDesc* __restric
     const int ncand = 1 + ndel + nins;
     float bs = 0.f; int bi = 0x7FFFFFFF;
     bool have = false;
-    for (int idx = lane; idx < ncand; idx += 64) {
+    for (int idx = lane; idx < ncand; idx += kCornerThreads) {
       float s;
       if (idx == 0) {
         s = HV(f.rq(nQ - 1), f.rt(nT - 1)) + sc;
@@ -74,6 +78,14 @@ __global__ __launch_bounds__(64) void dp_corner_kernel(const PairDesc* __restric
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
       float os = __shfl_xor(bs, o); int oi = __shfl_xor(bi, o); int oh = __shfl_xor((int)have, o);
+      bool take = oh && (!have || os > bs || (os == bs && oi < bi));
+      bs = take ? os : bs; bi = take ? oi : bi; have = have || oh;
+    }
+    // ... then across the waves, same rule
+    if ((lane & 63) == 0) { red_s[lane >> 6] = bs; red_i[lane >> 6] = bi; red_h[lane >> 6] = (int)have; }
+    __syncthreads();
+    for (int w = 0; w < kCornerThreads / 64; ++w) {
+      const float os = red_s[w]; const int oi = red_i[w]; const int oh = red_h[w];
       bool take = oh && (!have || os > bs || (os == bs && oi < bi));
       bs = take ? os : bs; bi = take ? oi : bi; have = have || oh;
     }
@@ -124,7 +136,7 @@ int launch_dp_corner(aln_batch* b) {
   proto.tcn = b->d_tcn; proto.deltab = b->d_deltab; proto.deltab_off = b->d_deltab_off; proto.instab = b->d_instab;
   const bool sub = b->sim_kind == ALN_SIM_SUBMATRIX;
   const bool tpos = b->gapdev.model != ALN_GAP_AFFINE_CONST;
-  hipLaunchKernelGGL(dp_corner_kernel, dim3(b->n_pairs), dim3(64), 0, b->ctx->stream, b->d_pairs, proto,
+  hipLaunchKernelGGL(dp_corner_kernel, dim3(b->n_pairs), dim3(kCornerThreads), 0, b->ctx->stream, b->d_pairs, proto,
                      sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr,
                      tpos ? b->d_tge : nullptr, b->d_H, b->d_P, sub ? nullptr : b->d_S, b->d_res,
                      (int)b->islocal, (int)!b->have_sub, (int)(b->direction == ALN_REV), (int)b->bug_b4, (int)b->ptr_mode, (int)b->h_mode);
