@@ -21,6 +21,7 @@
 //
 // Per cell: ~18 VALU instructions (was ~63); the kernel is HBM-write bound.  The pointer word needs 13 bits, so the
 // plane is written as uint16 (0xFFFF = untouched): 6 bytes per cell reach HBM instead of the algorithmic 8.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -61,13 +62,20 @@ __device__ __forceinline__ int wave_incl_max_key(int v) {
   return v;
 }
 
-template <int NW, int R, bool LOCAL, bool H16>
+// KBT = 13: value in bits 13..31 (|value| < 2^18).  KBT = 16 (local builds with 16-bit planes whose values provably fit 15
+// bits): the score is the key's high half and the pointer word its low half, so two cells pack into one plane word with a
+// single v_perm_b32 each and the pointer never has to be extracted.
+template <int NW, int R, bool LOCAL, bool H16, int KBT>
 __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
     const PairDesc* __restrict__ pairs, const uint8_t* __restrict__ qcodes, const uint8_t* __restrict__ tcodes,
     const int32_t* __restrict__ table32, float* __restrict__ Hbase, uint32_t* __restrict__ Pbase,
     PairResult* __restrict__ res, TagParams prm) {
   using namespace tag;
-  __shared__ int tab[32 * 32];          // substitution scores << 13
+  constexpr int KB = KBT;
+  constexpr int LOW = (1 << KB) - 1;
+  constexpr int NEGK = (KBT == 16) ? -(1 << 29) : tag::NEGK;   // value -8192 at KB = 16
+  static_assert(KBT == 13 || (KBT == 16 && LOCAL && H16), "the 16-bit key layout needs non-negative 15-bit scores");
+  __shared__ int tab[32 * 32];          // substitution scores << KB
   __shared__ uint8_t qcs[2048];         // the query's residue codes (Q <= 2048): one LDS byte per row instead of a global load
   __shared__ int xch[2][NW][4];
   __shared__ int red[NW][2];
@@ -128,10 +136,16 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if (inrange[r]) {
-        uint2 pv = make_uint2((pf[r][0] & 0xFFFFu) | (pf[r][1] << 16), (pf[r][2] & 0xFFFFu) | (pf[r][3] << 16));
+        // low halves of two pointer words (at KB = 16: of two whole keys): one v_perm_b32 per pair of cells
+        const uint2 pv = make_uint2(__builtin_amdgcn_perm(pf[r][1], pf[r][0], 0x05040100u), __builtin_amdgcn_perm(pf[r][3], pf[r][2], 0x05040100u));
         if (H16) {                              // local: 0 <= score < 2^16 -> uint16 plane (2 B/cell)
-          uint2 hv = make_uint2(((uint32_t)dk[r][0] >> KB) | (((uint32_t)dk[r][1] >> KB) << 16),
-                                ((uint32_t)dk[r][2] >> KB) | (((uint32_t)dk[r][3] >> KB) << 16));
+          uint2 hv;
+          if (KBT == 16)                        // the scores ARE the high halves
+            hv = make_uint2(__builtin_amdgcn_perm((uint32_t)dk[r][1], (uint32_t)dk[r][0], 0x07060302u),
+                            __builtin_amdgcn_perm((uint32_t)dk[r][3], (uint32_t)dk[r][2], 0x07060302u));
+          else
+            hv = make_uint2(((uint32_t)dk[r][0] >> KB) | (((uint32_t)dk[r][1] >> KB) << 16),
+                            ((uint32_t)dk[r][2] >> KB) | (((uint32_t)dk[r][3] >> KB) << 16));
           *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(Hbase) + pd.plane_off + ro + 256 * r) = hv;
         } else {
           const float sc = 1.0f / 8192.0f;     // exact: values are multiples of 2^13
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
         int kh = ((x == 0) ? uk : bk[r][x - 1]) + sK;
         if (LOCAL) kh = max(kh, ZKEY);
         int dnew = kh & ~LOW;
-        uint32_t pnew = (uint32_t)(kh & LOW);
+        uint32_t pnew = (KBT == 16) ? (uint32_t)kh : (uint32_t)(kh & LOW);   // KB = 16: the store takes the low half of the whole key
         if (masked) {
           int v1 = sK - colK;                                // column 1 (dpmatrix.h:421-426 / :593-599), pointer (0,0)
           if (LOCAL) v1 = max(v1, 0);
@@ -346,21 +360,36 @@ bool tag_path_legal(const aln_batch* b, const float* table, int n, const aln_gap
   return bound < 65536.0;
 }
 
+// The 16-bit key layout (score = high half of the key): local builds only (scores >= 0), best score + the A-space offset
+// ge * column below 2^15, and the most negative real candidate -(gi + ge * length + max|S|) above the kernel's -8192.
+static bool tag_key16_legal(const aln_batch* b) {
+  double maxs = 0;
+  for (float v : b->h_table) maxs = std::max(maxs, fabs((double)v));
+  const double gi = b->gap.gap_init, ge = b->gap.gap_extn;
+  const double L = (double)std::max(b->maxQ, b->maxT), best = maxs * (double)std::min(b->maxQ, b->maxT);
+  return best + ge * L + maxs < 32767.0 && gi + ge * L + maxs < 8000.0;
+}
+
 template <int NW, int R>
 static int launch_tag_variant(aln_batch* b, const TagParams& prm) {
   dim3 grid(b->n_pairs), block(64 * NW);
   hipStream_t st = b->ctx->stream;
-  if (b->islocal && b->h_mode == 1)
-    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, true, true>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
+  const bool k16 = b->islocal && b->h_mode == 1 && tag_key16_legal(b) && !getenv("ALN_NO_KEY16");
+  if (k16)
+    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, true, true, 16>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
+                       b->d_H, b->d_P, b->d_res, prm);
+  else if (b->islocal && b->h_mode == 1)
+    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, true, true, 13>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
                        b->d_H, b->d_P, b->d_res, prm);
   else if (b->islocal)
-    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, true, false>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
+    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, true, false, 13>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
                        b->d_H, b->d_P, b->d_res, prm);
   else
-    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, false, false>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
+    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, false, false, 13>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
                        b->d_H, b->d_P, b->d_res, prm);
   char nm[96];
-  snprintf(nm, sizeof nm, "dp_affine_tag_kernel<NW=%d,R=%d,%s%s>", NW, R, b->islocal ? "local" : "global", b->h_mode == 1 ? ",h16" : "");
+  snprintf(nm, sizeof nm, "dp_affine_tag_kernel<NW=%d,R=%d,%s%s%s>", NW, R, b->islocal ? "local" : "global", b->h_mode == 1 ? ",h16" : "",
+           k16 ? ",key16" : "");
   b->kernel_name = nm;
   ALN_HIP_CHECK(b->ctx, hipGetLastError());
   return ALN_OK;
