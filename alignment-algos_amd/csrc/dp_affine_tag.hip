@@ -96,6 +96,7 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
   __syncthreads();
 
   // ---- static per-column constants -----------------------------------------------------------------
+  int inm[R][4];        // -1 for interior columns 1 .. T-2, else 0
   int code4[R][4];      // byte offset of the column's residue in a table row
   int GK[R][4];         // (ge*c) << 13 | P_DEL | (2047 - c): d' + GK = key of A(c) = D + ge*c as a deletion source
   int EK[R][4];         // (ge*c + gi - ge) << 13: E(c+1) = prefmax - EK
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
       int code = kCodeTail;
       if (c < T) code = tc[c];
       code4[r][x] = code * 4;
+      inm[r][x] = ((unsigned)(c - 1) < (unsigned)(T - 2)) ? -1 : 0;
       GK[r][x] = ((ge * c) * (1 << KB)) | P_DEL | (TAGMAX - (c & TAGMAX));
       EK[r][x] = (ge * c + gi - ge) * (1 << KB);
     }
@@ -297,12 +299,14 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
         int dnew = kh & ~LOW;
         uint32_t pnew = (KBT == 16) ? (uint32_t)kh : (uint32_t)(kh & LOW);   // KB = 16: the store takes the low half of the whole key
         if (masked) {
-          int v1 = sK - colK;                                // column 1 (dpmatrix.h:421-426 / :593-599), pointer (0,0)
-          if (LOCAL) v1 = max(v1, 0);
-          const bool is1 = c == 1;
-          dnew = is1 ? v1 : dnew; pnew = is1 ? (uint32_t)ORIGIN_INS : pnew;
-          const bool in = (unsigned)(c - 1) < (unsigned)(T - 2);
-          dnew = in ? dnew : 0; pnew = in ? pnew : kNullPtr;
+          if (r == 0 && x == 1) {                            // column 1 (dpmatrix.h:421-426 / :593-599), pointer (0,0): lane 0 of wave 0
+            int v1 = sK - colK;
+            if (LOCAL) v1 = max(v1, 0);
+            const bool is1 = c == 1;
+            dnew = is1 ? v1 : dnew; pnew = is1 ? (uint32_t)ORIGIN_INS : pnew;
+          }
+          dnew &= inm[r][x];                                 // columns 0 and >= T-1: score 0, null pointer
+          pnew |= ~(uint32_t)inm[r][x];
         }
         dk[r][x] = dnew; pf[r][x] = pnew;
       }
