@@ -10,6 +10,7 @@
 struct Formats {
   struct FastaOut { FastaOut(int len = 60) : line_length(len) {} int line_length; };
   struct PIROut { PIROut(int len = 60) : line_length(len) {} int line_length; };
+  struct HMAPOut { HMAPOut(const char* sm = "", int len = 60) : line_length(len), submatrix(sm) {} int line_length; std::string submatrix; };
   struct FastaIn {
     FastaIn(const char* cs = "", bool flag = true) : head_tail(flag), find_me(cs) {}
     bool head_tail;

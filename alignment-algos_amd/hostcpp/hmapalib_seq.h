@@ -69,6 +69,24 @@ class HMAPSequence : public Sequence<HMAPElem*> {
   ~HMAPSequence() { for (size_t i = 0; i < size(); ++i) delete (*this)[i]; }
   std::string de_field, sr_field;
   float evd1_field, evd2_field;
+  // one character per element: '^' / '$', H / E for a confident helix / strand (probability and confidence >= 0.5), h / e for a
+  // weak one, ' ' otherwise (hmapalib_seq.cpp:245-270)
+  const std::string* getSSEString() const {
+    if (sse_string.empty()) {
+      for (size_t i = 0; i < size(); ++i) {
+        const HMAPElem* el = (*this)[i];
+        char sse;
+        const float helix = el->p_helix(), strand = el->p_strand(), coil = el->p_coil(), confid = el->sse_confid;
+        if (el->isHead()) sse = SequenceElem::Head;
+        else if (el->isTail()) sse = SequenceElem::Tail;
+        else if (helix > strand && helix > coil) sse = (helix < .5 || confid < .5) ? 'h' : 'H';
+        else if (strand > helix && strand > coil) sse = (strand < .5 || confid < .5) ? 'e' : 'E';
+        else sse = ' ';
+        sse_string.push_back(sse);
+      }
+    }
+    return &sse_string;
+  }
   // loop positions (p_coil > 0.3) are not suboptimal regions, everything else including the sentinels is (hmapalib_seq.cpp:272-282)
   void getDefaultFlags(SuboptFlags& sof) {
     sof.Set(0, true);
@@ -108,6 +126,7 @@ class HMAPSequence : public Sequence<HMAPElem*> {
     if (rest != "//") throw std::string("end of profile '//' not found");
   }
  private:
+  mutable std::string sse_string;
   HMAPSequence(const HMAPSequence&);
   HMAPSequence& operator=(const HMAPSequence&);
 };

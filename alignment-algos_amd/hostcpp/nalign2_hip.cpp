@@ -3,7 +3,7 @@
 // template's default flags (loops excluded) or a flag file, or UnconstrainedNearOptimal (-ucw); FASTA or PIR output.
 // Same flags and parameter handling as the reference driver.  Differences: the template is read as an HMAP profile (the
 // reference's SMAPSequence also loads a PDB structure through the Troll library, which Hmap2Eval never looks at);
-// -crcw (experimental, reads out of bounds in the reference: crcw.h:366-402) and the HMAP output format are refused; -kscw runs
+// -crcw (experimental, reads out of bounds in the reference: crcw.h:366-402) is refused; -kscw runs
 // the engine's KSConstrainedNearOptimal (parity unpinned).  The reference binary cannot be built here, so this driver's stdout has no golden; its pieces
 // (HMAP parser, Hmap2Eval, DPMatrix, Optimal, cw, writers) are each checked against the oracle / real reference.
 #include <ctime>
@@ -17,6 +17,7 @@
 #include "fastaio.h"
 #include "formats.h"
 #include "hmap2_eval.h"
+#include "hmapio.h"
 #include "kscw.h"
 #include "optimal.h"
 #include "pirio.h"
@@ -115,8 +116,9 @@ int main(int argc, const char** argv) {
       case oPIR:
         cout << Formats::PIROut(app_params.line_length) << alignments;
         break;
-      default:
-        throw string("HMAP output is not available on this engine");
+      case oHMAP:
+        cout << Formats::HMAPOut(ali_params.submatrix_fn.c_str(), app_params.line_length) << alignments;
+        break;
     }
     cerr << endl;
     cerr << "time for alignment was (sec) " << (t2 - t1) / (double)CLOCKS_PER_SEC << endl;
