@@ -36,65 +36,78 @@ static void usage() {
   exit(0);
 }
 
+namespace {
+
+struct Settings {
+  AliParams ali;
+  ApplicationParams app;
+  NOaliParams noa;
+  bool optimal_only;
+  string fasta;
+};
+
+// defaults <- ~/.hmaprc <- -top file <- --KEY value overrides, in the reference driver's order (aa_ali.cpp:33-58)
+Settings read_settings(int argc, const char** argv) {
+  if (argc == 0) usage();
+  Argv args(argc, argv);
+  if (args.help()) usage();
+  Settings s;
+  string topfile;
+  if (args.getSwitch("-top", false)) args.getSwitch("-top", 1) >> topfile;
+  s.optimal_only = args.getSwitch("-opt", true);
+  RCfile rc;
+  rc >> s.ali >> s.app >> s.noa;
+  if (!topfile.empty()) {
+    RCfile top(topfile);
+    top >> s.ali >> s.app;
+  }
+  args >> s.ali >> s.app >> s.noa;
+  if (args.count() != 1) usage();
+  s.fasta = args.getArg(0).str();
+  return s;
+}
+
+template <class Set>
+void print_alignments(const Settings& s, Set& alignments) {
+  if (s.app.output_format == oFASTA) cout << Formats::FastaOut(s.app.line_length) << alignments;
+  else if (s.app.output_format == oPIR) cout << Formats::PIROut(s.app.line_length) << alignments;
+  else { cerr << "Cannot use this format!\n"; exit(-1); }
+}
+
+}  // namespace
+
 int main(int argc, const char** argv) {
   try {
-    clock_t t0 = clock();
-    if (argc == 0) usage();
-    Argv args(argc, argv);
-    if (args.help()) usage();
-    string topfile;
-    if (args.getSwitch("-top", false)) args.getSwitch("-top", 1) >> topfile;
-    bool optflag = args.getSwitch("-opt", true);
+    const clock_t started = clock();
+    Settings s = read_settings(argc, argv);
 
-    AliParams ali_params;
-    ApplicationParams app_params;
-    NOaliParams noa_params;
-    RCfile default_rc;
-    default_rc >> ali_params >> app_params >> noa_params;
-    if (!topfile.empty()) {
-      RCfile top_rc(topfile);
-      top_rc >> ali_params >> app_params;
-    }
-    args >> ali_params >> app_params >> noa_params;
-    if (args.count() != 1) usage();
-
-    AASequence query, templ;
-    ifstream seqs(args.getArg(0).str().c_str());
+    // the FIRST record is the template, the messages are the reference's
+    AASequence templ, query;
+    ifstream in(s.fasta.c_str());
     cerr << "Reading in query profile" << endl;
-    seqs >> Formats::FastaIn() >> templ;
+    in >> Formats::FastaIn() >> templ;
     cerr << "Reading in template profile" << endl;
-    seqs >> Formats::FastaIn() >> query;
+    in >> Formats::FastaIn() >> query;
 
-    BlosumMatrix blosum(ali_params.submatrix_fn.c_str());
-    AAEval ge(ali_params, blosum);
-
-    DPMatrix<AASequence, AASequence, AAEval> dpm(query, templ, ge, fwd, ali_params.align_type);
+    BlosumMatrix blosum(s.ali.submatrix_fn.c_str());
+    AAEval scoring(s.ali, blosum);
+    DPMatrix<AASequence, AASequence, AAEval> dpm(query, templ, scoring, fwd, s.ali.align_type);
     cout << dpm << endl;
 
-    clock_t t1 = clock();
-    Optimal<AASequence, AASequence, AAEval> opt(ali_params.align_type);
-    AlignmentSet<AASequence, AASequence, AAEval> alignments(dpm, opt);
-    if (!optflag) {
-      SuboptFlags subopt(true, templ.size());
-      ConstrainedNearOptimal<AASequence, AASequence, AAEval> cno(noa_params, subopt);
-      cno.enumerate(dpm, alignments);
+    const clock_t aligned_from = clock();
+    Optimal<AASequence, AASequence, AAEval> best(s.ali.align_type);
+    AlignmentSet<AASequence, AASequence, AAEval> alignments(dpm, best);
+    if (!s.optimal_only) {
+      SuboptFlags everywhere(true, templ.size());
+      ConstrainedNearOptimal<AASequence, AASequence, AAEval> near_optimal(s.noa, everywhere);
+      near_optimal.enumerate(dpm, alignments);
     }
     alignments.assignIdentity();
-    clock_t t2 = clock();
+    const clock_t finished = clock();
 
-    switch (app_params.output_format) {
-      case oFASTA:
-        cout << Formats::FastaOut(app_params.line_length) << alignments;
-        break;
-      case oPIR:
-        cout << Formats::PIROut(app_params.line_length) << alignments;
-        break;
-      default:
-        cerr << "Cannot use this format!\n";
-        exit(-1);
-    }
-    cout << "time for alignment was (sec) " << (t2 - t1) / (double)CLOCKS_PER_SEC << endl;
-    cout << "total cpu time was (sec) " << (t2 - t0) / (double)CLOCKS_PER_SEC << endl << endl;
+    print_alignments(s, alignments);
+    cout << "time for alignment was (sec) " << (finished - aligned_from) / (double)CLOCKS_PER_SEC << endl;
+    cout << "total cpu time was (sec) " << (finished - started) / (double)CLOCKS_PER_SEC << endl << endl;
   } catch (string e) {
     cerr << e << endl;
     exit(-1);
