@@ -61,6 +61,23 @@ __device__ __forceinline__ int wave_incl_max_key(int v) {
   v = max(v, tdpp<0x143, 0xC>(ident, v));
   return v;
 }
+// the same scan over R independent values, stage by stage
+template <int R>
+__device__ __forceinline__ void wave_incl_max_keys(int (&v)[R]) {
+  const int ident = (int)0x80000000;
+#pragma unroll
+  for (int r = 0; r < R; ++r) v[r] = max(v[r], tdpp<0x111>(ident, v[r]));
+#pragma unroll
+  for (int r = 0; r < R; ++r) v[r] = max(v[r], tdpp<0x112>(ident, v[r]));
+#pragma unroll
+  for (int r = 0; r < R; ++r) v[r] = max(v[r], tdpp<0x114>(ident, v[r]));
+#pragma unroll
+  for (int r = 0; r < R; ++r) v[r] = max(v[r], tdpp<0x118>(ident, v[r]));
+#pragma unroll
+  for (int r = 0; r < R; ++r) v[r] = max(v[r], tdpp<0x142, 0xA>(ident, v[r]));
+#pragma unroll
+  for (int r = 0; r < R; ++r) v[r] = max(v[r], tdpp<0x143, 0xC>(ident, v[r]));
+}
 
 // KBT = 13: value in bits 13..31 (|value| < 2^18).  KBT = 16 (local builds with 16-bit planes whose values provably fit 15
 // bits): the score is the key's high half and the pointer word its low half, so two cells pack into one plane word with a
@@ -77,12 +94,17 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
   static_assert(KBT == 13 || (KBT == 16 && LOCAL && H16), "the 16-bit key layout needs non-negative 15-bit scores");
   __shared__ int tab[32 * 32];          // substitution scores << KB
   __shared__ uint8_t qcs[2048];         // the query's residue codes (Q <= 2048): one LDS byte per row instead of a global load
-  __shared__ int xch[2][NW][4];
+  __shared__ __attribute__((aligned(16))) int xch[2][NW][4];
   __shared__ int red[NW][2];
 
+  // R = 4 needs ~170 VGPRs, which would let the dispatcher place up to 3 waves on a SIMD.  A batch of 1024 pairs x 2 waves
+  // is exactly 2 waves per SIMD, but the dispatcher does not spread them evenly on its own (3 on some SIMDs, 1 on others:
+  // measured +20 % kernel time, and it varies with unrelated code changes).  Allocating >= 184 VGPRs caps every SIMD at 2.
+  if constexpr (R == 4) asm volatile("" ::: "v183");
   const PairDesc pd = pairs[blockIdx.x];
   const int Q = pd.Q, T = pd.T, ld = pd.ld;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: the exchange loop and the boundary tests stay scalar
   const int W0 = w * 256 * R;
   const int cb = W0 + 4 * lane;
   const int gi = prm.gi, ge = prm.ge;
@@ -135,6 +157,8 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
 
   auto store_row = [&](int i) {
     const size_t ro = (size_t)i * ld + cb;
+    uint16_t* __restrict__ h16row = reinterpret_cast<uint16_t*>(Hbase) + pd.plane_off + (size_t)i * ld;   // wave-uniform row bases
+    uint16_t* __restrict__ prow = P + (size_t)i * ld;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if (inrange[r]) {
@@ -148,13 +172,13 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
           else
             hv = make_uint2(((uint32_t)dk[r][0] >> KB) | (((uint32_t)dk[r][1] >> KB) << 16),
                             ((uint32_t)dk[r][2] >> KB) | (((uint32_t)dk[r][3] >> KB) << 16));
-          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(Hbase) + pd.plane_off + ro + 256 * r) = hv;
+          *reinterpret_cast<uint2*>(h16row + (unsigned)(cb + 256 * r)) = hv;
         } else {
           const float sc = 1.0f / 8192.0f;     // exact: values are multiples of 2^13
           float4 hv = make_float4((float)dk[r][0] * sc, (float)dk[r][1] * sc, (float)dk[r][2] * sc, (float)dk[r][3] * sc);
           *reinterpret_cast<float4*>(H + ro + 256 * r) = hv;
         }
-        *reinterpret_cast<uint2*>(P + ro + 256 * r) = pv;
+        *reinterpret_cast<uint2*>(prow + (unsigned)(cb + 256 * r)) = pv;
       }
     }
   };
@@ -166,17 +190,21 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
   // computed and passes as (dB,pB)): prefix-scan preparation for the next row, exchange, local-max tracking, store.
   auto finish_row = [&](int i, int dB, uint32_t pB) {
     int sk = NEGK;     // scalar carry: prefix key over this wave's earlier groups
+    int ik[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
 #pragma unroll
       for (int x = 0; x < 4; ++x) ak[r][x] = dk[r][x] + GK[r][x];
       int a0 = ak[r][0];
       if (r == 0) a0 = (lane == 0) ? NEGK : a0;             // column 0 is never a source; wave firsts are folded below
-      const int tk = max(max(a0, ak[r][1]), max(ak[r][2], ak[r][3]));
-      const int ik = wave_incl_max_key(tk);
-      const int ek = tdpp<0x138>(NEGK, ik);                 // wave_shr:1 -> exclusive
+      ik[r] = max(max(a0, ak[r][1]), max(ak[r][2], ak[r][3]));
+    }
+    wave_incl_max_keys<R>(ik);   // the R scans in lock-step: each DPP stage's hazard slots hold the other groups
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int ek = tdpp<0x138>(NEGK, ik[r]);              // wave_shr:1 -> exclusive
       cvk[r] = max(sk, ek);
-      sk = max(sk, __builtin_amdgcn_readlane(ik, 63));
+      sk = max(sk, __builtin_amdgcn_readlane(ik[r], 63));
     }
     if (NW > 1) {
       if (lane == 63) { xch[par][w][0] = sk; xch[par][w][1] = dB; xch[par][w][2] = (int)pB; }
@@ -184,15 +212,20 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (w > 0) {
         int fk = NEGK;                                      // prefix over columns 1 .. W0-1
-        for (int v = 0; v < w; ++v) {
-          fk = max(fk, xch[par][v][0]);
-          if (v < w - 1) {
-            const int Cn = (v + 1) * 256 * R;
-            fk = max(fk, xch[par][v][1] + (((ge * Cn) * (1 << KB)) | P_DEL | (TAGMAX - Cn)));
+        int d0 = 0; uint32_t p0 = kNullPtr;
+#pragma unroll
+        for (int v = 0; v < NW - 1; ++v) {
+          if (v < w) {                                      // wave-uniform; one ds_read_b128 per earlier wave
+            const int4 t = *reinterpret_cast<const int4*>(&xch[par][v][0]);
+            fk = max(fk, t.x);
+            if (v < w - 1) {
+              const int Cn = (v + 1) * 256 * R;
+              fk = max(fk, t.y + (((ge * Cn) * (1 << KB)) | P_DEL | (TAGMAX - Cn)));
+            } else {
+              d0 = t.y; p0 = (uint32_t)t.z;
+            }
           }
         }
-        const int d0 = xch[par][w - 1][1];
-        const uint32_t p0 = (uint32_t)xch[par][w - 1][2];
         if (lane == 0) { dk[0][0] = d0; pf[0][0] = p0; ak[0][0] = d0 + GK[0][0]; }
         const int f2 = max(fk, d0 + (((ge * W0) * (1 << KB)) | P_DEL | (TAGMAX - W0)));
 #pragma unroll
@@ -253,6 +286,10 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
     const int colK = prm.free_ins ? 0 : FK;                                     // column 1: one insertion from the origin
 
     int bk[R][4];
+    // the 32 table entries of this row's residue, one per lane; cells fetch theirs with ds_bpermute (fixed per-lane
+    // addresses = code * 4) instead of an address add + ds_read per cell
+    const int rowv = tab_at(qrow, (lane & 31) * 4);
+    auto sim_at = [&](int c4) -> int { return __builtin_amdgcn_ds_bpermute(c4, rowv); };
     // cell phase: source column c -> best key of target column c+1 (before the target's similarity)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -271,7 +308,7 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
     // boundary target (first column of the next wave), finished by this wave's lane 63
     int dB = 0; uint32_t pB = kNullPtr;
     if (NW > 1) {
-      int kh = bk[R - 1][3] + tab_at(qrow, codeB4);
+      int kh = bk[R - 1][3] + sim_at(codeB4);
       if (LOCAL) kh = max(kh, ZKEY);
       const bool in = CB <= T - 2;
       dB = in ? (kh & ~LOW) : 0;
@@ -281,34 +318,41 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int x = 0; x < 4; ++x) gmx[r][x] = max(gmx[r][x], dk[r][x] + RK);
+      for (int x = 0; x < 4; ++x) {
+        gmx[r][x] = max(gmx[r][x], dk[r][x] + RK);
+        asm volatile("" : "+v"(gmx[r][x]));                  // pin the update here: sunk to the loop latch it keeps row i-1 alive next to
+      }                                                      // row i and costs a register copy per cell
     // shift one column right, add the target column's similarity, clip, split into score and pointer word
     int prev_k = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      int uk = tdpp<0x138>(0, bk[r][3]);                   // wave_shr:1
-      if (r > 0) uk = (lane == 0) ? prev_k : uk;
+      // wave_shr:1; lane 0 takes the previous group's last column (its "old" operand), group 0's lane 0 is a don't-care
+      const int uk = (r == 0) ? __builtin_amdgcn_update_dpp(0, bk[r][3], 0x138, 0xF, 0xF, true) : tdpp<0x138>(prev_k, bk[r][3]);
       prev_k = __builtin_amdgcn_readlane(bk[r][3], 63);
       const bool masked = (r == 0 && W0 == 0) || (W0 + 256 * (r + 1) > T - 1);   // wave-uniform
+      int sK1 = 0;
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
-        const int c = cb + 256 * r + x;
-        const int sK = tab_at(qrow, code4[r][x]);
+        const int sK = sim_at(code4[r][x]);
+        if (r == 0 && x == 1) sK1 = sK;
         int kh = ((x == 0) ? uk : bk[r][x - 1]) + sK;
         if (LOCAL) kh = max(kh, ZKEY);
-        int dnew = kh & ~LOW;
-        uint32_t pnew = (KBT == 16) ? (uint32_t)kh : (uint32_t)(kh & LOW);   // KB = 16: the store takes the low half of the whole key
-        if (masked) {
-          if (r == 0 && x == 1) {                            // column 1 (dpmatrix.h:421-426 / :593-599), pointer (0,0): lane 0 of wave 0
-            int v1 = sK - colK;
-            if (LOCAL) v1 = max(v1, 0);
-            const bool is1 = c == 1;
-            dnew = is1 ? v1 : dnew; pnew = is1 ? (uint32_t)ORIGIN_INS : pnew;
-          }
-          dnew &= inm[r][x];                                 // columns 0 and >= T-1: score 0, null pointer
-          pnew |= ~(uint32_t)inm[r][x];
+        dk[r][x] = kh & ~LOW;
+        pf[r][x] = (KBT == 16) ? (uint32_t)kh : (uint32_t)(kh & LOW);   // KB = 16: the store takes the low half of the whole key
+      }
+      if (masked) {                                          // one scalar branch per group; only the groups holding column 0/1 or columns >= T-1 pay
+        asm volatile("" ::: "memory");                       // (if-converted, this block costs two v_cndmask per cell on every group)
+        if (r == 0) {                                        // column 1 (dpmatrix.h:421-426 / :593-599), pointer (0,0): lane 0 of wave 0
+          int v1 = sK1 - colK;
+          if (LOCAL) v1 = max(v1, 0);
+          const bool is1 = cb == 0;
+          dk[0][1] = is1 ? v1 : dk[0][1]; pf[0][1] = is1 ? (uint32_t)ORIGIN_INS : pf[0][1];
         }
-        dk[r][x] = dnew; pf[r][x] = pnew;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          dk[r][x] &= inm[r][x];                             // columns 0 and >= T-1: score 0, null pointer
+          pf[r][x] |= ~(uint32_t)inm[r][x];
+        }
       }
     }
     finish_row(i, dB, pB);
