@@ -277,19 +277,28 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
   }
 
   // ---- interior rows 2 .. Q-2 (dpmatrix.h:447-486 / :607-649) ---------------------------------------------
-  int qcode_next = (Q >= 4) ? (int)qcs[2] : 0;
+  // Similarity values travel through a three-stage pipeline so that no LDS round trip sits on a row's critical path:
+  // the residue code of row i+2, the table row of row i+1 (one entry per lane) and the per-cell values of row i
+  // (ds_bpermute with fixed per-lane addresses = code * 4, so no address arithmetic per cell) are all fetched at the top
+  // of iteration i and consumed one stage later.
+  const int lane_row4 = (lane & 31) * 4;
+  int code_n1 = (Q >= 5) ? (int)qcs[3] : 0;                                     // residue of row i+1
+  int rowv_next = tab_at(((Q >= 4) ? (int)qcs[2] : 0) * 128, lane_row4);        // table row of row i
   for (int i = 2; i <= Q - 2; ++i) {
-    const int qrow = qcode_next * 128;
-    if (i + 1 <= Q - 2) qcode_next = (int)qcs[i + 1];
+    const int rowv = rowv_next;
+    rowv_next = tab_at(code_n1 * 128, lane_row4);
+    code_n1 = (int)qcs[min(i + 2, Q - 1)];                                      // (clamped: only rows <= Q-2 are consumed)
     const int FK = (gi + ge * (i - 2)) * (1 << KB);                                   // F = gmx - FK
     const int RK = ((ge * (i - 1)) * (1 << KB)) | P_INS | (TAGMAX - (i - 1));         // key(D[i-1][c] + ge (i-1), insertion from row i-1)
     const int colK = prm.free_ins ? 0 : FK;                                     // column 1: one insertion from the origin
 
     int bk[R][4];
-    // the 32 table entries of this row's residue, one per lane; cells fetch theirs with ds_bpermute (fixed per-lane
-    // addresses = code * 4) instead of an address add + ds_read per cell
-    const int rowv = tab_at(qrow, (lane & 31) * 4);
-    auto sim_at = [&](int c4) -> int { return __builtin_amdgcn_ds_bpermute(c4, rowv); };
+    int sv[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) sv[r][x] = __builtin_amdgcn_ds_bpermute(code4[r][x], rowv);
+    const int svB = (NW > 1) ? __builtin_amdgcn_ds_bpermute(codeB4, rowv) : 0;
     // cell phase: source column c -> best key of target column c+1 (before the target's similarity)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
     // boundary target (first column of the next wave), finished by this wave's lane 63
     int dB = 0; uint32_t pB = kNullPtr;
     if (NW > 1) {
-      int kh = bk[R - 1][3] + sim_at(codeB4);
+      int kh = bk[R - 1][3] + svB;
       if (LOCAL) kh = max(kh, ZKEY);
       const bool in = CB <= T - 2;
       dB = in ? (kh & ~LOW) : 0;
@@ -333,7 +342,7 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
       int sK1 = 0;
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
-        const int sK = sim_at(code4[r][x]);
+        const int sK = sv[r][x];
         if (r == 0 && x == 1) sK1 = sK;
         int kh = ((x == 0) ? uk : bk[r][x - 1]) + sK;
         if (LOCAL) kh = max(kh, ZKEY);
