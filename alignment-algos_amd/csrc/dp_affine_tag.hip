@@ -155,31 +155,37 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
   int lmax = 0; uint32_t lpos = 0;
   int par = 0;
 
+  // 16-bit planes are stored through buffer descriptors that cover ONE ROW (base = the row, num_records = 2*ld bytes),
+  // rebuilt per row with scalar instructions: lanes of a partial last group (columns >= ld) are dropped by the memory
+  // pipeline's range check -- no exec-mask branch around the stores.  (The scalar-offset operand cannot carry the row:
+  // gfx950 includes it in the range check, measured with tools/scratch/buf_test.hip.)
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  uint16_t* const H16p = reinterpret_cast<uint16_t*>(Hbase) + pd.plane_off;
+  const int vo16 = cb * 2;              // this lane's byte offset inside a 16-bit row
   auto store_row = [&](int i) {
     const size_t ro = (size_t)i * ld + cb;
-    uint16_t* __restrict__ h16row = reinterpret_cast<uint16_t*>(Hbase) + pd.plane_off + (size_t)i * ld;   // wave-uniform row bases
-    uint16_t* __restrict__ prow = P + (size_t)i * ld;
+    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(P + (size_t)i * ld, 0, ld * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(H16p + (size_t)i * ld, 0, ld * 2, 0x00020000);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      if (inrange[r]) {
-        // low halves of two pointer words (at KB = 16: of two whole keys): one v_perm_b32 per pair of cells
-        const uint2 pv = make_uint2(__builtin_amdgcn_perm(pf[r][1], pf[r][0], 0x05040100u), __builtin_amdgcn_perm(pf[r][3], pf[r][2], 0x05040100u));
-        if (H16) {                              // local: 0 <= score < 2^16 -> uint16 plane (2 B/cell)
-          uint2 hv;
-          if (KBT == 16)                        // the scores ARE the high halves
-            hv = make_uint2(__builtin_amdgcn_perm((uint32_t)dk[r][1], (uint32_t)dk[r][0], 0x07060302u),
-                            __builtin_amdgcn_perm((uint32_t)dk[r][3], (uint32_t)dk[r][2], 0x07060302u));
-          else
-            hv = make_uint2(((uint32_t)dk[r][0] >> KB) | (((uint32_t)dk[r][1] >> KB) << 16),
-                            ((uint32_t)dk[r][2] >> KB) | (((uint32_t)dk[r][3] >> KB) << 16));
-          *reinterpret_cast<uint2*>(h16row + (unsigned)(cb + 256 * r)) = hv;
+      // low halves of two pointer words (at KB = 16: of two whole keys): one v_perm_b32 per pair of cells
+      const u32x2 pv = {__builtin_amdgcn_perm(pf[r][1], pf[r][0], 0x05040100u), __builtin_amdgcn_perm(pf[r][3], pf[r][2], 0x05040100u)};
+      if (H16) {                              // local: 0 <= score < 2^16 -> uint16 plane (2 B/cell)
+        u32x2 hv;
+        if (KBT == 16) {                      // the scores ARE the high halves
+          hv.x = __builtin_amdgcn_perm((uint32_t)dk[r][1], (uint32_t)dk[r][0], 0x07060302u);
+          hv.y = __builtin_amdgcn_perm((uint32_t)dk[r][3], (uint32_t)dk[r][2], 0x07060302u);
         } else {
-          const float sc = 1.0f / 8192.0f;     // exact: values are multiples of 2^13
-          float4 hv = make_float4((float)dk[r][0] * sc, (float)dk[r][1] * sc, (float)dk[r][2] * sc, (float)dk[r][3] * sc);
-          *reinterpret_cast<float4*>(H + ro + 256 * r) = hv;
+          hv.x = ((uint32_t)dk[r][0] >> KB) | (((uint32_t)dk[r][1] >> KB) << 16);
+          hv.y = ((uint32_t)dk[r][2] >> KB) | (((uint32_t)dk[r][3] >> KB) << 16);
         }
-        *reinterpret_cast<uint2*>(prow + (unsigned)(cb + 256 * r)) = pv;
+        __builtin_amdgcn_raw_buffer_store_b64(hv, rsH, vo16 + 512 * r, 0, 0);
+      } else if (inrange[r]) {
+        const float sc = 1.0f / 8192.0f;     // exact: values are multiples of 2^13
+        float4 hv = make_float4((float)dk[r][0] * sc, (float)dk[r][1] * sc, (float)dk[r][2] * sc, (float)dk[r][3] * sc);
+        *reinterpret_cast<float4*>(H + ro + 256 * r) = hv;
       }
+      __builtin_amdgcn_raw_buffer_store_b64(pv, rsP, vo16 + 512 * r, 0, 0);
     }
   };
   auto tab_at = [&](int qrow, int c4) -> int {
