@@ -44,6 +44,7 @@ constexpr int ORIGIN_INS = P_INS | TAGMAX;  // pointer (0, j-1): cells of column
 struct TagParams {
   int gi, ge;
   int free_del, free_ins;
+  int alt_prio;
 };
 
 template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
@@ -84,6 +85,7 @@ __device__ __forceinline__ void wave_incl_max_keys(int (&v)[R]) {
 // single v_perm_b32 each and the pointer never has to be extracted.
 template <int NW, int R, bool LOCAL, bool H16, int KBT>
 __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
+
     const PairDesc* __restrict__ pairs, const uint8_t* __restrict__ qcodes, const uint8_t* __restrict__ tcodes,
     const int32_t* __restrict__ table32, float* __restrict__ Hbase, uint32_t* __restrict__ Pbase,
     PairResult* __restrict__ res, TagParams prm) {
@@ -288,9 +290,17 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
   // (ds_bpermute with fixed per-lane addresses = code * 4, so no address arithmetic per cell) are all fetched at the top
   // of iteration i and consumed one stage later.
   const int lane_row4 = (lane & 31) * 4;
+  const int hwslot = (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_ID.WAVE_ID: this wave's slot on its SIMD
   int code_n1 = (Q >= 5) ? (int)qcs[3] : 0;                                     // residue of row i+1
   int rowv_next = tab_at(((Q >= 4) ? (int)qcs[2] : 0) * 128, lane_row4);        // table row of row i
   for (int i = 2; i <= Q - 2; ++i) {
+    // The SIMD's arbiter favours its older wave: of the 4 pairs of a CU the first finishes after 2.4 ms, the last after
+    // 3.3 ms, and the SIMD idles behind the early finishers.  Alternating the user priority row by row (by the parity of
+    // the wave's hardware slot) evens that out: -6 % on a lone launch.  Off by default, because launches that overlap on
+    // two streams (bench.py) fill those gaps better and lose with it (ALN_TAG_ALT_PRIO=1 turns it on).
+    if (prm.alt_prio) {
+      if ((i ^ hwslot) & 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+    }
     const int rowv = rowv_next;
     rowv_next = tab_at(code_n1 * 128, lane_row4);
     code_n1 = (int)qcs[min(i + 2, Q - 1)];                                      // (clamped: only rows <= Q-2 are consumed)
@@ -464,6 +474,7 @@ int launch_dp_affine_tag(aln_batch* b) {
   prm.ge = (int)b->gap.gap_extn;
   prm.free_del = b->gapdev.free_del;
   prm.free_ins = b->gapdev.free_ins;
+  { const char* e = getenv("ALN_TAG_ALT_PRIO"); prm.alt_prio = (e && *e == '1') ? 1 : 0; }
   const int ld = (b->maxT + 3) & ~3;
   int nw = 0, r = 0;
   if (const char* e = getenv("ALN_DP_VARIANT")) sscanf(e, "%d,%d", &nw, &r);
