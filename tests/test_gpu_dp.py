@@ -617,3 +617,62 @@ def test_optimal_enqueue_collect(blosum62):
         ms = b.dp_ms_history(8)
         assert len(ms) == 2 and (ms > 0).all()
         b.close()
+
+
+def test_row_alternating_priority_is_invisible(blosum62, monkeypatch):
+    """ALN_TAG_ALT_PRIO=1 (s_setprio alternating per row, a scheduling hint of the tagged kernel) changes no cell."""
+    alpha, table = blosum62
+    pairs = [homolog_pair(77000 + n, ln) for n, ln in enumerate((1500, 1100, 700))] + [random_pair(77100, 1990, 1800)]
+    qs, ts = [p[0] for p in pairs], [p[1] for p in pairs]
+    planes = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("ALN_TAG_ALT_PRIO", flag)
+        b = aln_amd.Batch(gpu_util.ctx(), qs, ts)
+        b.dp_submatrix(alpha, table, 3, 11, 1, aln_amd.FWD, aln_amd.DP_FAST)
+        assert "dp_affine_tag" in b.kernel_name() and "R=4" in b.kernel_name()
+        sc, lists, st = b.optimal()
+        planes.append([b.get_cells(p) for p in range(len(qs))] + [sc, lists])
+        b.close()
+    for p in range(len(qs)):
+        for x, y in zip(planes[0][p], planes[1][p]):
+            assert np.array_equal(x, y)
+    assert np.array_equal(planes[0][-2], planes[1][-2])
+    assert all(np.array_equal(a, b) for a, b in zip(planes[0][-1], planes[1][-1]))
+    # and against the oracle for one of them
+    S = orc.sim_submatrix(qs[2], ts[2], alpha, table)
+    rc, D0, PQ0, PT0 = orc.dp_build(S, orc.Gap(3, 11, 1))
+    D, PQ, PT = planes[1][2]
+    assert np.array_equal(D.view(np.uint32), D0.view(np.uint32)) and np.array_equal(PQ, PQ0) and np.array_equal(PT, PT0)
+
+
+def test_two_contexts_on_two_streams_overlap(blosum62):
+    """bench.py alternates its steps over two resident batches, each with its own context and HIP stream, so that their
+    launches overlap on the GPU: both give the results of a lone batch, step after step."""
+    alpha, table = blosum62
+    pairs = [homolog_pair(78000 + n, 1200 + 100 * (n % 5)) for n in range(24)]
+    qs, ts = [p[0] for p in pairs], [p[1] for p in pairs]
+    lone = aln_amd.Batch(gpu_util.ctx(), qs, ts)
+    lone.dp_submatrix(alpha, table, 3, 11, 1, aln_amd.FWD, aln_amd.DP_FAST)
+    sc0, lists0, st0 = lone.optimal()
+    cells0 = lone.get_cells(5)
+    lone.close()
+    ctxs = [aln_amd.Context(0), aln_amd.Context(0)]        # each context creates its own non-blocking HIP stream
+    bs = [aln_amd.Batch(c, qs, ts) for c in ctxs]
+    for b in bs:
+        b.dp_submatrix(alpha, table, 3, 11, 1, aln_amd.FWD, aln_amd.DP_FAST)
+    for step in range(6):
+        b = bs[step % 2]
+        if step >= 2:
+            sc, cnt, st = b.optimal_collect()
+            assert np.array_equal(sc.view(np.uint32), sc0.view(np.uint32)) and np.array_equal(st, st0)
+            assert cnt.tolist() == [len(x) for x in lists0]
+        b.reevaluate()
+        b.optimal_enqueue()
+    for b in bs:
+        sc, cnt, st = b.optimal_collect()
+        assert np.array_equal(sc.view(np.uint32), sc0.view(np.uint32))
+        for x, y in zip(b.get_cells(5), cells0):
+            assert np.array_equal(x, y)
+        b.close()
+    for c in ctxs:
+        c.close()
