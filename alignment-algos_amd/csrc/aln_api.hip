@@ -104,7 +104,7 @@ int aln_batch_create(aln_ctx* ctx, const aln_seqs* queries, const aln_seqs* temp
     int64_t Q = b->q_offsets[qi + 1] - b->q_offsets[qi], T = b->t_offsets[ti + 1] - b->t_offsets[ti];
     if (Q < 2 || T < 2) { delete b; return ALN_E_ARG; }          // every sequence carries '^' and '$'
     if (Q > kMaxLen || T > kMaxLen) { delete b; return ALN_E_TOO_LONG; }
-    d.Q = (int)Q; d.T = (int)T; d.ld = ((int)T + 3) & ~3;
+    d.Q = (int)Q; d.T = (int)T; d.ld = row_stride((int)T);
     d.q_seq = qi; d.t_seq = ti;
     d.q_off = b->q_offsets[qi]; d.t_off = b->t_offsets[ti];
     d.plane_off = off;

@@ -14,6 +14,9 @@ constexpr uint32_t kNullPtr = 0xFFFFFFFFu;   // packed (prev_q<<16 | prev_t) of 
 constexpr int kMaxLen = 65534;               // 16-bit packed indices, 0xFFFF reserved for DPCell::null
 constexpr int kCodeHead = 30, kCodeTail = 31;   // residue codes of '^' and '$'; alphabet codes are 0..n-1 (n <= 30)
 constexpr int kNeg = -(1 << 28);             // "-infinity" of the integer kernels (leaves headroom for subtractions)
+// Row stride of a pair's planes in cells: T rounded up to 8, so fp32 rows are 32-byte and uint16 rows 16-byte aligned and a
+// lane's 8-cell store never straddles the end of a row.
+inline int row_stride(int T) { return (T + 7) & ~7; }
 
 // One DPMatrix of the batch, as the kernels see it.
 struct PairDesc {

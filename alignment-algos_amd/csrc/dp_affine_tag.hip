@@ -83,9 +83,8 @@ __device__ __forceinline__ void wave_incl_max_keys(int (&v)[R]) {
 // KBT = 13: value in bits 13..31 (|value| < 2^18).  KBT = 16 (local builds with 16-bit planes whose values provably fit 15
 // bits): the score is the key's high half and the pointer word its low half, so two cells pack into one plane word with a
 // single v_perm_b32 each and the pointer never has to be extracted.
-template <int NW, int R, bool LOCAL, bool H16, int KBT>
+template <int NW, int R, bool LOCAL, bool H16, int KBT, int X>
 __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
-
     const PairDesc* __restrict__ pairs, const uint8_t* __restrict__ qcodes, const uint8_t* __restrict__ tcodes,
     const int32_t* __restrict__ table32, float* __restrict__ Hbase, uint32_t* __restrict__ Pbase,
     PairResult* __restrict__ res, TagParams prm) {
@@ -94,21 +93,23 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
   constexpr int LOW = (1 << KB) - 1;
   constexpr int NEGK = (KBT == 16) ? -(1 << 29) : tag::NEGK;   // value -8192 at KB = 16
   static_assert(KBT == 13 || (KBT == 16 && LOCAL && H16), "the 16-bit key layout needs non-negative 15-bit scores");
+  static_assert(X == 4 || X == 8, "a lane owns 4 or 8 consecutive columns of each group");
+  constexpr int GW = 64 * X;            // columns of one group (one lane-contiguous stretch of a row)
   __shared__ int tab[32 * 32];          // substitution scores << KB
   __shared__ uint8_t qcs[2048];         // the query's residue codes (Q <= 2048): one LDS byte per row instead of a global load
   __shared__ __attribute__((aligned(16))) int xch[2][NW][4];
   __shared__ int red[NW][2];
 
-  // R = 4 needs ~170 VGPRs, which would let the dispatcher place up to 3 waves on a SIMD.  A batch of 1024 pairs x 2 waves
+  // 16 cells per lane need ~170 VGPRs, which would let the dispatcher place up to 3 waves on a SIMD.  A batch of 1024 pairs x 2 waves
   // is exactly 2 waves per SIMD, but the dispatcher does not spread them evenly on its own (3 on some SIMDs, 1 on others:
   // measured +20 % kernel time, and it varies with unrelated code changes).  Allocating >= 184 VGPRs caps every SIMD at 2.
-  if constexpr (R == 4) asm volatile("" ::: "v183");
+  if constexpr (R * X == 16) asm volatile("" ::: "v183");
   const PairDesc pd = pairs[blockIdx.x];
   const int Q = pd.Q, T = pd.T, ld = pd.ld;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: the exchange loop and the boundary tests stay scalar
-  const int W0 = w * 256 * R;
-  const int cb = W0 + 4 * lane;
+  const int W0 = w * GW * R;
+  const int cb = W0 + X * lane;
   const int gi = prm.gi, ge = prm.ge;
   float* __restrict__ H = Hbase + pd.plane_off;
   uint16_t* __restrict__ P = reinterpret_cast<uint16_t*>(Pbase) + pd.plane_off;   // 16-bit pointer words (mode 1)
@@ -120,17 +121,17 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
   __syncthreads();
 
   // ---- static per-column constants -----------------------------------------------------------------
-  int inm[R][4];        // -1 for interior columns 1 .. T-2, else 0
-  int code4[R][4];      // byte offset of the column's residue in a table row
-  int GK[R][4];         // (ge*c) << 13 | P_DEL | (2047 - c): d' + GK = key of A(c) = D + ge*c as a deletion source
-  int EK[R][4];         // (ge*c + gi - ge) << 13: E(c+1) = prefmax - EK
+  int inm[R][X];        // -1 for interior columns 1 .. T-2, else 0
+  int code4[R][X];      // byte offset of the column's residue in a table row
+  int GK[R][X];         // (ge*c) << 13 | P_DEL | (2047 - c): d' + GK = key of A(c) = D + ge*c as a deletion source
+  int EK[R][X];         // (ge*c + gi - ge) << 13: E(c+1) = prefmax - EK
   bool inrange[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    inrange[r] = (cb + 256 * r) < ld;
+    inrange[r] = (cb + GW * r) < ld;
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      const int c = cb + 256 * r + x;
+    for (int x = 0; x < X; ++x) {
+      const int c = cb + GW * r + x;
       int code = kCodeTail;
       if (c < T) code = tc[c];
       code4[r][x] = code * 4;
@@ -139,20 +140,20 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
       EK[r][x] = (ge * c + gi - ge) * (1 << KB);
     }
   }
-  const int CB = W0 + 256 * R;     // first column of the next wave = this wave's boundary target
+  const int CB = W0 + GW * R;     // first column of the next wave = this wave's boundary target
   int codeB4 = kCodeTail * 4;
   if (NW > 1 && CB < T) codeB4 = tc[CB] * 4;
 
-  int dk[R][4];         // D[i-1][c] << 13 (low bits zero)
-  int gmx[R][4];        // running max over k of key(D[k][c] + ge*k, insertion, 2047-k)
+  int dk[R][X];         // D[i-1][c] << 13 (low bits zero)
+  int gmx[R][X];        // running max over k of key(D[k][c] + ge*k, insertion, 2047-k)
   int cvk[R];           // lane-exclusive prefix key of the row in dk (A-space), per group
-  int ak[R][4];         // A-space keys of the row in dk: dk + GK (column 0 / wave firsts handled where they are used)
-  uint32_t pf[R][4];    // pointer words of the row being finished
+  int ak[R][X];         // A-space keys of the row in dk: dk + GK (column 0 / wave firsts handled where they are used)
+  uint32_t pf[R][X];    // pointer words of the row being finished
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     cvk[r] = NEGK;
 #pragma unroll
-    for (int x = 0; x < 4; ++x) { dk[r][x] = 0; gmx[r][x] = NEGK; pf[r][x] = kNullPtr; }
+    for (int x = 0; x < X; ++x) { dk[r][x] = 0; gmx[r][x] = NEGK; pf[r][x] = kNullPtr; }
   }
   int lmax = 0; uint32_t lpos = 0;
   int par = 0;
@@ -162,8 +163,13 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
   // pipeline's range check -- no exec-mask branch around the stores.  (The scalar-offset operand cannot carry the row:
   // gfx950 includes it in the range check, measured with tools/scratch/buf_test.hip.)
   typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   uint16_t* const H16p = reinterpret_cast<uint16_t*>(Hbase) + pd.plane_off;
   const int vo16 = cb * 2;              // this lane's byte offset inside a 16-bit row
+  auto store_words = [&](const uint32_t (&wd)[X / 2], __amdgpu_buffer_rsrc_t rs, int off) {
+    if constexpr (X == 4) { const u32x2 v = {wd[0], wd[1]}; __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, 0); }
+    else { const u32x4 v = {wd[0], wd[1], wd[2], wd[3]}; __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0); }
+  };
   auto store_row = [&](int i) {
     const size_t ro = (size_t)i * ld + cb;
     const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(P + (size_t)i * ld, 0, ld * 2, 0x00020000);
@@ -171,23 +177,23 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       // low halves of two pointer words (at KB = 16: of two whole keys): one v_perm_b32 per pair of cells
-      const u32x2 pv = {__builtin_amdgcn_perm(pf[r][1], pf[r][0], 0x05040100u), __builtin_amdgcn_perm(pf[r][3], pf[r][2], 0x05040100u)};
+      uint32_t pw[X / 2], hw[X / 2];
+#pragma unroll
+      for (int x = 0; x < X; x += 2) pw[x / 2] = __builtin_amdgcn_perm(pf[r][x + 1], pf[r][x], 0x05040100u);
       if (H16) {                              // local: 0 <= score < 2^16 -> uint16 plane (2 B/cell)
-        u32x2 hv;
-        if (KBT == 16) {                      // the scores ARE the high halves
-          hv.x = __builtin_amdgcn_perm((uint32_t)dk[r][1], (uint32_t)dk[r][0], 0x07060302u);
-          hv.y = __builtin_amdgcn_perm((uint32_t)dk[r][3], (uint32_t)dk[r][2], 0x07060302u);
-        } else {
-          hv.x = ((uint32_t)dk[r][0] >> KB) | (((uint32_t)dk[r][1] >> KB) << 16);
-          hv.y = ((uint32_t)dk[r][2] >> KB) | (((uint32_t)dk[r][3] >> KB) << 16);
-        }
-        __builtin_amdgcn_raw_buffer_store_b64(hv, rsH, vo16 + 512 * r, 0, 0);
+#pragma unroll
+        for (int x = 0; x < X; x += 2)
+          hw[x / 2] = (KBT == 16) ? __builtin_amdgcn_perm((uint32_t)dk[r][x + 1], (uint32_t)dk[r][x], 0x07060302u)   // the scores ARE the high halves
+                                  : (((uint32_t)dk[r][x] >> KB) | (((uint32_t)dk[r][x + 1] >> KB) << 16));
+        store_words(hw, rsH, vo16 + 2 * GW * r);
       } else if (inrange[r]) {
         const float sc = 1.0f / 8192.0f;     // exact: values are multiples of 2^13
-        float4 hv = make_float4((float)dk[r][0] * sc, (float)dk[r][1] * sc, (float)dk[r][2] * sc, (float)dk[r][3] * sc);
-        *reinterpret_cast<float4*>(H + ro + 256 * r) = hv;
+#pragma unroll
+        for (int x = 0; x < X; x += 4)
+          *reinterpret_cast<float4*>(H + ro + GW * r + x) =
+              make_float4((float)dk[r][x] * sc, (float)dk[r][x + 1] * sc, (float)dk[r][x + 2] * sc, (float)dk[r][x + 3] * sc);
       }
-      __builtin_amdgcn_raw_buffer_store_b64(pv, rsP, vo16 + 512 * r, 0, 0);
+      store_words(pw, rsP, vo16 + 2 * GW * r);
     }
   };
   auto tab_at = [&](int qrow, int c4) -> int {
@@ -202,10 +208,12 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
 #pragma unroll
     for (int r = 0; r < R; ++r) {
 #pragma unroll
-      for (int x = 0; x < 4; ++x) ak[r][x] = dk[r][x] + GK[r][x];
+      for (int x = 0; x < X; ++x) ak[r][x] = dk[r][x] + GK[r][x];
       int a0 = ak[r][0];
       if (r == 0) a0 = (lane == 0) ? NEGK : a0;             // column 0 is never a source; wave firsts are folded below
-      ik[r] = max(max(a0, ak[r][1]), max(ak[r][2], ak[r][3]));
+      int t0 = max(a0, ak[r][1]), t1 = max(ak[r][2], ak[r][3]);
+      if constexpr (X == 8) { t0 = max(max(t0, ak[r][4]), ak[r][5]); t1 = max(max(t1, ak[r][6]), ak[r][7]); }   // v_max3
+      ik[r] = max(t0, t1);
     }
     wave_incl_max_keys<R>(ik);   // the R scans in lock-step: each DPP stage's hazard slots hold the other groups
 #pragma unroll
@@ -227,7 +235,7 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
             const int4 t = *reinterpret_cast<const int4*>(&xch[par][v][0]);
             fk = max(fk, t.x);
             if (v < w - 1) {
-              const int Cn = (v + 1) * 256 * R;
+              const int Cn = (v + 1) * GW * R;
               fk = max(fk, t.y + (((ge * Cn) * (1 << KB)) | P_DEL | (TAGMAX - Cn)));
             } else {
               d0 = t.y; p0 = (uint32_t)t.z;
@@ -248,14 +256,16 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
     if (LOCAL) {
       int rm = 0;
 #pragma unroll
-      for (int r = 0; r < R; ++r) { rm = max(max(rm, dk[r][0]), dk[r][1]); rm = max(max(rm, dk[r][2]), dk[r][3]); }   // 2 x v_max3 per group
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int x = 0; x < X; x += 2) rm = max(max(rm, dk[r][x]), dk[r][x + 1]);   // v_max3 per two cells
       if (rm > lmax) {                                      // rare: resolve the first column of this lane at the new maximum
         lmax = rm;
         int cfirst = 0x7FFFFFFF;
 #pragma unroll
         for (int r = R - 1; r >= 0; --r)
 #pragma unroll
-          for (int x = 3; x >= 0; --x) cfirst = (dk[r][x] == rm) ? (cb + 256 * r + x) : cfirst;
+          for (int x = X - 1; x >= 0; --x) cfirst = (dk[r][x] == rm) ? (cb + GW * r + x) : cfirst;
         lpos = ((uint32_t)i << 16) | (uint32_t)cfirst;
       }
     }
@@ -278,7 +288,7 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int x = 0; x < 4; ++x) row1(cb + 256 * r + x, tab_at(qrow, code4[r][x]), dk[r][x], pf[r][x]);
+      for (int x = 0; x < X; ++x) row1(cb + GW * r + x, tab_at(qrow, code4[r][x]), dk[r][x], pf[r][x]);
     int dB = 0; uint32_t pB = kNullPtr;
     if (NW > 1) row1(CB, tab_at(qrow, codeB4), dB, pB);
     finish_row(1, dB, pB);
@@ -308,19 +318,19 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
     const int RK = ((ge * (i - 1)) * (1 << KB)) | P_INS | (TAGMAX - (i - 1));         // key(D[i-1][c] + ge (i-1), insertion from row i-1)
     const int colK = prm.free_ins ? 0 : FK;                                     // column 1: one insertion from the origin
 
-    int bk[R][4];
-    int sv[R][4];
+    int bk[R][X];
+    int sv[R][X];
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int x = 0; x < 4; ++x) sv[r][x] = __builtin_amdgcn_ds_bpermute(code4[r][x], rowv);
+      for (int x = 0; x < X; ++x) sv[r][x] = __builtin_amdgcn_ds_bpermute(code4[r][x], rowv);
     const int svB = (NW > 1) ? __builtin_amdgcn_ds_bpermute(codeB4, rowv) : 0;
     // cell phase: source column c -> best key of target column c+1 (before the target's similarity)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       int pv = cvk[r];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) {
+      for (int x = 0; x < X; ++x) {
         const int m = dk[r][x];
         int A = ak[r][x];
         if (r == 0 && x == 0) A = (cb == 0) ? NEGK : A;     // column 0 is never a source (dpmatrix.h:459 starts at t0+1)
@@ -333,7 +343,7 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
     // boundary target (first column of the next wave), finished by this wave's lane 63
     int dB = 0; uint32_t pB = kNullPtr;
     if (NW > 1) {
-      int kh = bk[R - 1][3] + svB;
+      int kh = bk[R - 1][X - 1] + svB;
       if (LOCAL) kh = max(kh, ZKEY);
       const bool in = CB <= T - 2;
       dB = in ? (kh & ~LOW) : 0;
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int x = 0; x < 4; ++x) {
+      for (int x = 0; x < X; ++x) {
         gmx[r][x] = max(gmx[r][x], dk[r][x] + RK);
         asm volatile("" : "+v"(gmx[r][x]));                  // pin the update here: sunk to the loop latch it keeps row i-1 alive next to
       }                                                      // row i and costs a register copy per cell
@@ -352,12 +362,12 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       // wave_shr:1; lane 0 takes the previous group's last column (its "old" operand), group 0's lane 0 is a don't-care
-      const int uk = (r == 0) ? __builtin_amdgcn_update_dpp(0, bk[r][3], 0x138, 0xF, 0xF, true) : tdpp<0x138>(prev_k, bk[r][3]);
-      prev_k = __builtin_amdgcn_readlane(bk[r][3], 63);
-      const bool masked = (r == 0 && W0 == 0) || (W0 + 256 * (r + 1) > T - 1);   // wave-uniform
+      const int uk = (r == 0) ? __builtin_amdgcn_update_dpp(0, bk[r][X - 1], 0x138, 0xF, 0xF, true) : tdpp<0x138>(prev_k, bk[r][X - 1]);
+      prev_k = __builtin_amdgcn_readlane(bk[r][X - 1], 63);
+      const bool masked = (r == 0 && W0 == 0) || (W0 + GW * (r + 1) > T - 1);   // wave-uniform
       int sK1 = 0;
 #pragma unroll
-      for (int x = 0; x < 4; ++x) {
+      for (int x = 0; x < X; ++x) {
         const int sK = sv[r][x];
         if (r == 0 && x == 1) sK1 = sK;
         int kh = ((x == 0) ? uk : bk[r][x - 1]) + sK;
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
           dk[0][1] = is1 ? v1 : dk[0][1]; pf[0][1] = is1 ? (uint32_t)ORIGIN_INS : pf[0][1];
         }
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
+        for (int x = 0; x < X; ++x) {
           dk[r][x] &= inm[r][x];                             // columns 0 and >= T-1: score 0, null pointer
           pf[r][x] |= ~(uint32_t)inm[r][x];
         }
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int x = 0; x < 4; ++x) { dk[r][x] = 0; pf[r][x] = kNullPtr; }
+      for (int x = 0; x < X; ++x) { dk[r][x] = 0; pf[r][x] = kNullPtr; }
     store_row(Q - 1);
   }
 
@@ -443,26 +453,26 @@ static bool tag_key16_legal(const aln_batch* b) {
   return best + ge * L + maxs < 32767.0 && gi + ge * L + maxs < 8000.0;
 }
 
-template <int NW, int R>
+template <int NW, int R, int X>
 static int launch_tag_variant(aln_batch* b, const TagParams& prm) {
   dim3 grid(b->n_pairs), block(64 * NW);
   hipStream_t st = b->ctx->stream;
   const bool k16 = b->islocal && b->h_mode == 1 && tag_key16_legal(b) && !getenv("ALN_NO_KEY16");
   if (k16)
-    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, true, true, 16>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
+    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, true, true, 16, X>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
                        b->d_H, b->d_P, b->d_res, prm);
   else if (b->islocal && b->h_mode == 1)
-    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, true, true, 13>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
+    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, true, true, 13, X>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
                        b->d_H, b->d_P, b->d_res, prm);
   else if (b->islocal)
-    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, true, false, 13>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
+    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, true, false, 13, X>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
                        b->d_H, b->d_P, b->d_res, prm);
   else
-    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, false, false, 13>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
+    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, false, false, 13, X>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
                        b->d_H, b->d_P, b->d_res, prm);
   char nm[96];
-  snprintf(nm, sizeof nm, "dp_affine_tag_kernel<NW=%d,R=%d,%s%s%s>", NW, R, b->islocal ? "local" : "global", b->h_mode == 1 ? ",h16" : "",
-           k16 ? ",key16" : "");
+  snprintf(nm, sizeof nm, "dp_affine_tag_kernel<NW=%d,R=%d,%s%s%s%s>", NW, R, X == 8 ? "X=8," : "", b->islocal ? "local" : "global",
+           b->h_mode == 1 ? ",h16" : "", k16 ? ",key16" : "");
   b->kernel_name = nm;
   ALN_HIP_CHECK(b->ctx, hipGetLastError());
   return ALN_OK;
@@ -475,21 +485,23 @@ int launch_dp_affine_tag(aln_batch* b) {
   prm.free_del = b->gapdev.free_del;
   prm.free_ins = b->gapdev.free_ins;
   { const char* e = getenv("ALN_TAG_ALT_PRIO"); prm.alt_prio = (e && *e == '1') ? 1 : 0; }
-  const int ld = (b->maxT + 3) & ~3;
-  int nw = 0, r = 0;
-  if (const char* e = getenv("ALN_DP_VARIANT")) sscanf(e, "%d,%d", &nw, &r);
+  const int ld = row_stride(b->maxT);
+  // variant = waves per pair, groups per lane, consecutive columns a lane owns in a group (ALN_DP_VARIANT="NW,R[,X]")
+  int nw = 0, r = 0, x = 4;
+  if (const char* e = getenv("ALN_DP_VARIANT")) sscanf(e, "%d,%d,%d", &nw, &r, &x);
   if (nw == 0) {
     if (ld <= 256) { nw = 1; r = 1; }
     else if (ld <= 512) { nw = 2; r = 1; }
     else if (ld <= 1024) { nw = 4; r = 1; }
-    else { nw = 2; r = 4; }          // measured on config 2: 750 GCUPS vs 741 (4,2) and 673 (8,1)
+    else { nw = 2; r = 2; x = 8; }   // 2 waves x 2 groups x 8 columns per lane: half the row scans of (2,4,4)
   }
-  if (256 * nw * r < ld) return ALN_E_TOO_LONG;
-#define ALN_V(NW_, R_) if (nw == NW_ && r == R_) return launch_tag_variant<NW_, R_>(b, prm)
-  ALN_V(1, 1); ALN_V(1, 2); ALN_V(1, 4); ALN_V(1, 8);
-  ALN_V(2, 1); ALN_V(2, 2); ALN_V(2, 4);
-  ALN_V(4, 1); ALN_V(4, 2);
-  ALN_V(8, 1);
+  if (64 * x * nw * r < ld) return ALN_E_TOO_LONG;
+#define ALN_V(NW_, R_, X_) if (nw == NW_ && r == R_ && x == X_) return launch_tag_variant<NW_, R_, X_>(b, prm)
+  ALN_V(1, 1, 4); ALN_V(1, 2, 4); ALN_V(1, 4, 4); ALN_V(1, 8, 4);
+  ALN_V(2, 1, 4); ALN_V(2, 2, 4); ALN_V(2, 4, 4);
+  ALN_V(4, 1, 4); ALN_V(4, 2, 4);
+  ALN_V(8, 1, 4);
+  ALN_V(1, 4, 8); ALN_V(2, 1, 8); ALN_V(2, 2, 8); ALN_V(4, 1, 8);
 #undef ALN_V
   return ALN_E_ARG;
 }

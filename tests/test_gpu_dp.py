@@ -216,7 +216,7 @@ def test_random_batch_vs_oracle(mode, blosum62):
 
 
 @pytest.mark.parametrize("kernel", ["tag", "int"])
-@pytest.mark.parametrize("variant", ["1,2", "1,8", "2,1", "2,4", "4,1", "4,2", "8,1"])
+@pytest.mark.parametrize("variant", ["1,2", "1,8", "2,1", "2,4", "4,1", "4,2", "8,1", "1,4,8", "2,1,8", "2,2,8", "4,1,8"])
 def test_kernel_variants_agree(variant, kernel, blosum62, monkeypatch):
     """Every (waves per pair, groups per lane) instantiation of both row-sweep kernels (tagged keys, Q,T <= 2048;
     plain int32 with explicit arg-max, up to 8192) gives the oracle's planes."""
@@ -224,8 +224,10 @@ def test_kernel_variants_agree(variant, kernel, blosum62, monkeypatch):
     monkeypatch.setenv("ALN_DP_VARIANT", variant)
     if kernel == "int":
         monkeypatch.setenv("ALN_NO_TAG_KERNEL", "1")
-    nw, r = [int(x) for x in variant.split(",")]
-    cap = 256 * nw * r - 2
+    nw, r, xc = ([int(x) for x in variant.split(",")] + [4])[:3]
+    if kernel == "int" and xc != 4:
+        pytest.skip("8 columns per lane and group exist in the tagged kernel only")
+    cap = 64 * xc * nw * r - 2
     qs, ts = [], []
     for n, tl in enumerate([cap, cap - 1, cap - 255, max(cap - 300, 5), 7]):
         if n % 2:
@@ -239,6 +241,7 @@ def test_kernel_variants_agree(variant, kernel, blosum62, monkeypatch):
         b = aln_amd.Batch(gpu_util.ctx(), qs, ts)
         b.dp_submatrix(alpha, table, mode, 11, 1, aln_amd.FWD, aln_amd.DP_FAST)
         assert "NW=%d,R=%d" % (nw, r) in b.kernel_name() and ("dp_affine_%s" % kernel) in b.kernel_name()
+        assert ("X=8" in b.kernel_name()) == (xc == 8)
         for p, (q, t) in enumerate(zip(qs, ts)):
             S = orc.sim_submatrix(q, t, alpha, table)
             rc, D0, PQ0, PT0 = orc.dp_build(S, orc.Gap(mode, 11, 1))
@@ -629,7 +632,7 @@ def test_row_alternating_priority_is_invisible(blosum62, monkeypatch):
         monkeypatch.setenv("ALN_TAG_ALT_PRIO", flag)
         b = aln_amd.Batch(gpu_util.ctx(), qs, ts)
         b.dp_submatrix(alpha, table, 3, 11, 1, aln_amd.FWD, aln_amd.DP_FAST)
-        assert "dp_affine_tag" in b.kernel_name() and "R=4" in b.kernel_name()
+        assert "dp_affine_tag" in b.kernel_name() and "NW=2" in b.kernel_name()
         sc, lists, st = b.optimal()
         planes.append([b.get_cells(p) for p in range(len(qs))] + [sc, lists])
         b.close()
