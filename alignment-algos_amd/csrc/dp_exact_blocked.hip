@@ -512,7 +512,7 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
                                                                  const float* __restrict__ tgi, const float* __restrict__ tge,
                                                                  float* __restrict__ Hbase, uint32_t* __restrict__ Pbase,
                                                                  const float* __restrict__ Sbase, PairResult* __restrict__ res, int rev,
-                                                                 float* __restrict__ scratch_base) {
+                                                                 float* __restrict__ scratch_base, int alt_prio) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float2* tg = reinterpret_cast<float2*>(lds);          // (tgi, tge) in frame order, PT entries
   float* rowloc0 = lds + 2 * PT;                         // rows a-1 / a of the current tile, index k - kbase
@@ -563,8 +563,20 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
     __syncthreads();
     const int ntiles = (nT - 1 + kTW - 1) / kTW;
 
+    const int hwslot = (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_ID.WAVE_ID
     for (int a0 = 1; a0 <= nQ - 1; a0 += kBR) {
       const int a_end = (a0 + kBR - 1 < nQ - 1) ? a0 + kBR - 1 : nQ - 1;
+      // The SIMD arbiter favours its oldest wave, so of the 4 pairs resident on a CU the first would run ahead and the last
+      // finish alone on a half-empty SIMD (measured on the tagged kernel).  Rotating the user priority over
+      // the 4 wave slots of a SIMD, one step per row block, keeps the pairs abreast: 854 -> 771 ms on config 3.
+      if (alt_prio) {
+        switch (((a0 / kBR) + hwslot) & 3) {
+          case 0: __builtin_amdgcn_s_setprio(0); break;
+          case 1: __builtin_amdgcn_s_setprio(1); break;
+          case 2: __builtin_amdgcn_s_setprio(2); break;
+          default: __builtin_amdgcn_s_setprio(3); break;
+        }
+      }
       for (int cb = 0; cb < ntiles; ++cb) {
         const int kbase = kTW * cb;                    // = b0 - 1: first near source column of the tile
         const int bc = kbase + 1 + tid;                // this thread's column
@@ -899,10 +911,12 @@ int launch_dp_exact_blocked(aln_batch* b) {
   if (tiled) {
     const size_t lds = ((size_t)2 * ptt + 2 * kTLoc) * sizeof(float);
     const int rev = (int)(b->direction == ALN_REV);
+    const char* ape = getenv("ALN_EXACT_ALT_PRIO");
+    const int alt_prio = (ape && *ape == '0') ? 0 : 1;   // on unless ALN_EXACT_ALT_PRIO=0
 #define ALN_TLAUNCH(PTC, TP, LC)                                                                                                 \
     hipLaunchKernelGGL((dp_exact_tiled_kernel<PTC, TP, LC>), dim3(b->n_pairs), dim3(kTW), lds, ctx->stream, b->d_pairs, proto,     \
                        sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr,                        \
-                       tpos ? b->d_tge : nullptr, b->d_H, b->d_P, sub ? nullptr : b->d_S, b->d_res, rev, b->d_xscratch)
+                       tpos ? b->d_tge : nullptr, b->d_H, b->d_P, sub ? nullptr : b->d_S, b->d_res, rev, b->d_xscratch, alt_prio)
 #define ALN_TLAUNCH_P(PTC)                                                                                                       \
     do { if (tpos) { if (b->islocal) ALN_TLAUNCH(PTC, true, true); else ALN_TLAUNCH(PTC, true, false); }                         \
          else { if (b->islocal) ALN_TLAUNCH(PTC, false, true); else ALN_TLAUNCH(PTC, false, false); } } while (0)
