@@ -2,8 +2,8 @@
 """bench.py — BASELINE.json config 2 on N MI355X: batched local affine-gap DP (BLOSUM62, 11/1) over 1024
 synthetic 2000 x 2000 pairs per GPU, DP build + find_max + pointer traceback, through the C ABI.
 
-A step = one pass of the hot path (aln_batch_dp + aln_batch_optimal) over the resident batch; sequences are
-uploaded to HBM before the timed region.  Pairs are independent, so ranks own disjoint batches (weak scaling)
+A step = one pass of the hot path (aln_batch_dp + aln_batch_optimal) over the resident batch of 1024 pairs, issued as
+--split launches that rotate over --streams HIP streams (see main()); sequences are uploaded to HBM before the timed region.  Pairs are independent, so ranks own disjoint batches (weak scaling)
 and the only collective is one all_gather of the fp32 scores per step (RCCL over xGMI).
 
 Prints ONE JSON line: metric GCUPS = sum |q|*|t| of all ranks / wall seconds (max over ranks), plus
@@ -90,8 +90,10 @@ def main():
     ap.add_argument("--pairs", type=int, default=1024, help="pairs per GPU (config 2: 1024)")
     ap.add_argument("--length", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batches", type=int, default=2,
-                    help="resident batches the steps alternate over, each on its own HIP stream (1 = one batch, one stream)")
+    ap.add_argument("--streams", "--batches", dest="batches", type=int, default=3,
+                    help="HIP streams (contexts) the launches rotate over (1 = everything on one stream)")
+    ap.add_argument("--split", type=int, default=2,
+                    help="launches a step's batch is processed in (sub-batches of pairs/split pairs; 1 = one launch per step)")
     args = ap.parse_args()
 
     import torch
@@ -125,13 +127,26 @@ def main():
 
     mode, gi, ge = aln_amd.LOCAL, 11, 1
     qs, ts = make_workload(rank, args.pairs, args.length)
-    # Resident batches of the same workload, each with its own context on its own HIP stream.  Steps alternate over them
-    # (step k -> batch k % n): the O(Q+T) corner kernel and the traceback of one step then share the GPU with the DP
-    # kernel of the next instead of running alone on it.  Every step still builds, scans and traces one whole batch.
+    # How a step's batch reaches the GPU.  The batch of `pairs` pairs is processed as `split` sub-batches (pairs/split pairs
+    # each, one launch sequence each) and consecutive launches rotate over `streams` contexts, each with its own HIP stream:
+    # launch j runs sub-batch j % split on stream j % streams.  Launches of different streams overlap, so there are always
+    # undispatched pairs to take the SIMD slots that finished pairs free (a lone 1024-pair launch fills the GPU exactly
+    # once and leaves early-finishing SIMDs idle: DESIGN.md 4.1), and the O(Q+T) corner kernel and the traceback run
+    # beside the next DP kernel.  Measured on one box, ms per 1024 pairs: 1 stream 3.3; 2 streams x 1024 pairs 2.8-3.8
+    # depending on the phase the two streams fall into; 3 streams x 512 pairs 2.77 every time.  Every step still builds,
+    # scans and traces all `pairs` pairs; every (stream, sub-batch) combination that occurs has its own resident planes.
     nb = max(1, args.batches)
+    split = args.split if (args.split >= 1 and args.pairs % max(1, args.split) == 0) else 1
+    ph = args.pairs // split
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nb - 1)]
     ctxs = [aln_amd.Context(local_rank, st.cuda_stream) for st in streams]
-    batches = [aln_amd.Batch(c, qs, ts) for c in ctxs]   # sequences -> HBM, planes allocated (outside the timed region)
+    units = {}                                              # (stream, sub-batch) -> resident batch object
+    j = 0
+    while (j % nb, j % split) not in units:
+        sidx, h = j % nb, j % split
+        units[(sidx, h)] = aln_amd.Batch(ctxs[sidx], qs[h * ph:(h + 1) * ph], ts[h * ph:(h + 1) * ph])   # sequences -> HBM, planes allocated
+        j += 1
+    batches = list(units.values())
     # codes + substitution table -> HBM and the first build (the DPMatrix constructors); timed steps then
     # re-run the build on the resident inputs exactly like DPMatrix::reevaluate (dpmatrix.h:213-218)
     for bt in batches:
@@ -151,19 +166,24 @@ def main():
     def collect():
         sc, cnt, status = queue.pop(0).optimal_collect()
         if world > 1:                                       # the one collective of the path: all ranks' scores (RCCL)
-            gather_scores(sc, args.pairs * world, world, rank, device=None if rehearse else dev, stream=side)
+            gather_scores(sc, len(sc) * world, world, rank, device=None if rehearse else dev, stream=side)
         return sc, status
 
-    def step():
-        bt = batches[count[0] % nb]
+    def launch():                                           # one sub-batch: build + find_max + traceback, results to the host
+        bt = units[(count[0] % nb, count[0] % split)]
         count[0] += 1
-        if bt in queue:                                     # its previous step must be read out before its planes are rebuilt
-            while bt in queue:
-                collect()
+        while bt in queue:                                  # its previous results must be read out before its planes are rebuilt
+            collect()
         bt.reevaluate()
         bt.optimal_enqueue()
         queue.append(bt)
         return collect() if len(queue) > nb else (None, None)
+
+    def step():                                             # all sub-batches of the batch
+        out = (None, None)
+        for _ in range(split):
+            out = launch()
+        return out
 
     def drain():
         out = (None, None)
@@ -186,21 +206,24 @@ def main():
     sc, status = drain()
     fence()
     elapsed = time.perf_counter() - t0
-    # HIP events around the DP kernel of each timed step, on the stream it was launched on
-    per = [min(len(range(j, args.steps, nb)), 64) for j in range(nb)]
-    first = (args.warmup) % nb                              # batch of the first timed step
-    kernel_ms = np.concatenate([batches[(first + j) % nb].dp_ms_history(per[j]) for j in range(nb) if per[j] > 0])
+    # HIP events around the DP kernel of each timed launch, on the stream it was launched on
+    n_launch = args.steps * split
+    first = args.warmup * split                             # index of the first timed launch
+    per = {}
+    for j in range(first, first + n_launch):
+        k = (j % nb, j % split)
+        per[k] = per.get(k, 0) + 1
+    kernel_ms = np.concatenate([units[k].dp_ms_history(min(n, 64)) for k, n in per.items()])
     assert (status == 0).all()
-    if nb > 1:                                              # same inputs in every resident batch -> identical results
-        ref_sc = None
-        for bt in batches:
-            bt.reevaluate()
-            s_b, _, st_b = bt.optimal()
-            assert (st_b == 0).all()
-            if ref_sc is None:
-                ref_sc = np.array(s_b, copy=True)
-            else:
-                assert np.array_equal(ref_sc, s_b), "resident batches disagree"
+    ref_sc = {}                                             # same inputs -> identical results, whichever stream ran them
+    for (sidx, h), bt in units.items():
+        bt.reevaluate()
+        s_b, _, st_b = bt.optimal()
+        assert (st_b == 0).all()
+        if h not in ref_sc:
+            ref_sc[h] = np.array(s_b, copy=True)
+        else:
+            assert np.array_equal(ref_sc[h], s_b), "resident copies of a sub-batch disagree"
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -223,10 +246,13 @@ def main():
     except Exception:
         pass
 
-    cells_per_step = batch.cells() * world
+    first_of = {}
+    for (sidx, h), bt in units.items():
+        first_of.setdefault(h, bt)
+    cells_per_step = sum(first_of[h].cells() for h in range(split)) * world
     value = cells_per_step * args.steps / elapsed / 1e9
     dp_ms = float(np.mean(kernel_ms))
-    algo_bytes = batch.algorithmic_bytes()
+    algo_bytes = batch.algorithmic_bytes()                  # of one launch (one sub-batch)
     if nb == 1:
         achieved = algo_bytes / (dp_ms * 1e-3) / 1e9
         how = "algorithmic bytes per launch / average launch duration (HIP events on the launch stream)"
@@ -235,14 +261,16 @@ def main():
         # also reports) is not the time the device spends per launch.  The aggregate rate of the kernel is bounded from
         # below by all timed launches' algorithmic bytes over the wall time of the timed region, which also contains the
         # corner and traceback kernels; that lower bound is what is reported.
-        achieved = algo_bytes * args.steps / elapsed / 1e9
-        how = ("%d launches overlap: algorithmic bytes of all timed launches / wall time of the timed region (lower bound; "
-               "kernel_ms is one launch's own duration while it shares the GPU)" % nb)
+        achieved = algo_bytes * args.steps * split / elapsed / 1e9
+        how = ("launches of %d streams overlap: algorithmic bytes of all timed launches / wall time of the timed region (lower "
+               "bound; kernel_ms is one launch's own duration while it shares the GPU)" % nb)
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tfile) and args.pairs == 1024 and args.length == 2000:   # the PMC pass was taken on exactly this launch
+    if os.path.exists(tfile) and args.length == 2000:       # only if the PMC pass was taken on exactly this launch shape
         try:
-            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tfile))
+            if tj.get("launch_pairs", 1024) == ph:
+                traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     out = {
@@ -253,7 +281,7 @@ def main():
         "config": {"workload": "config 2: %d synthetic %dx%d pairs per GPU, local SW, affine gap 11/1, BLOSUM62 submatrix evaluator, "
                                "DP build + find_max + traceback" % (args.pairs, args.length, args.length),
                    "pairs_per_gpu": args.pairs, "parallelism": "pair-batch sharded, %d rank(s), all_gather of scores" % world,
-                   "kernel": batch.kernel_name(), "resident_batches": nb},
+                   "kernel": batch.kernel_name(), "launch_pairs": ph, "launches_per_step": split, "streams": nb},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "kernel_ms": round(dp_ms, 3), "concurrent_launches": nb, "achieved_is": how,
