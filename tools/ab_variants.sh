@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 cp alignment-algos_amd/libalnhip.so /tmp/libalnhip_default.so
 for N in "$@"; do
   cp alignment-algos_amd/build/var/libalnhip_$N.so alignment-algos_amd/libalnhip.so
-  python bench.py --steps ${ALN_AB_STEPS:-10} --warmup 3 --no-cpu-baseline --batches ${ALN_AB_BATCHES:-1} $ALN_AB_EXTRA > gpurun_out/ab_$N.log 2>&1
+  python bench.py --steps ${ALN_AB_STEPS:-10} --warmup 3 --no-cpu-baseline --streams ${ALN_AB_BATCHES:-1} --split ${ALN_AB_SPLIT:-1} $ALN_AB_EXTRA > gpurun_out/ab_$N.log 2>&1
   python - "$N" <<'PY'
 import json,sys
 n=sys.argv[1]
