@@ -31,8 +31,6 @@
 namespace aln {
 
 namespace tag {
-constexpr int KB = 13;                      // low bits: prio(2) | tag(11)
-constexpr int LOW = (1 << KB) - 1;
 constexpr int TAGMAX = 2047;
 constexpr int P_MATCH = 3 << 11, P_DEL = 2 << 11, P_INS = 1 << 11;
 constexpr int NEGK = -(1 << 30);            // value -2^17: below every real value (|v| < 2^16), headroom for one subtraction

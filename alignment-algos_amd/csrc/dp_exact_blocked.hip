@@ -81,7 +81,7 @@ __device__ __forceinline__ void scan_range(ScanState<NS>& s, const float* __rest
   constexpr int NA = NS - JJ;
   constexpr int UNR = (NS == 1) ? 2 : kBC / 4;   // one-slot kernels: a short body keeps the register count down
   for (int kc = k0; kc < k1; kc += kBC) {
-#pragma unroll(UNR)
+#pragma unroll UNR
     for (int u4 = 0; u4 < kBC; u4 += 4) {
       const float4 p4 = *reinterpret_cast<const float4*>(prev + kc + u4);
       float4 ga = {0.f, 0.f, 0.f, 0.f}, gb = {0.f, 0.f, 0.f, 0.f};
