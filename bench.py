@@ -85,12 +85,12 @@ def cpu_baseline(qs, ts, mode, gi, ge):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--pairs", type=int, default=1024, help="pairs per GPU (config 2: 1024)")
     ap.add_argument("--length", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", "--batches", dest="batches", type=int, default=3,
+    ap.add_argument("--streams", "--batches", dest="batches", type=int, default=4,
                     help="HIP streams (contexts) the launches rotate over (1 = everything on one stream)")
     ap.add_argument("--split", type=int, default=2,
                     help="launches a step's batch is processed in (sub-batches of pairs/split pairs; 1 = one launch per step)")
@@ -132,9 +132,10 @@ def main():
     # launch j runs sub-batch j % split on stream j % streams.  Launches of different streams overlap, so there are always
     # undispatched pairs to take the SIMD slots that finished pairs free (a lone 1024-pair launch fills the GPU exactly
     # once and leaves early-finishing SIMDs idle: DESIGN.md 4.1), and the O(Q+T) corner kernel and the traceback run
-    # beside the next DP kernel.  Measured on one box, ms per 1024 pairs: 1 stream 3.3; 2 streams x 1024 pairs 2.8-3.8
-    # depending on the phase the two streams fall into; 3 streams x 512 pairs 2.77 every time.  Every step still builds,
-    # scans and traces all `pairs` pairs; every (stream, sub-batch) combination that occurs has its own resident planes.
+    # beside the next DP kernel.  Measured on one box, ms per 1024 pairs: 1 stream x 1024 pairs 3.3-3.6; 2 streams x 1024
+    # pairs 2.8-3.8 depending on the phase the two streams fall into; 3 streams x 512 pairs 2.70-2.97; 4 streams x 512
+    # pairs 2.69-2.76 (the default); 5 x 512: 3.57; 3 x 256: 3.76.  Every step still builds, scans and traces all `pairs`
+    # pairs; every (stream, sub-batch) combination that occurs has its own resident planes.
     nb = max(1, args.batches)
     split = args.split if (args.split >= 1 and args.pairs % max(1, args.split) == 0) else 1
     ph = args.pairs // split
