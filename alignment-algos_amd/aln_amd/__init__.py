@@ -398,10 +398,11 @@ class Batch:
         return res
 
     def enumerate_all(self, kind, number_suboptimal, delta_ratio, flags=None, K=None, user_limit=0, node_cap=0, ali_cap=0,
-                      want_pairs=True, raise_on_overflow=True):
+                      want_pairs=True, raise_on_overflow=True, k_limit=0):
         """aln_batch_enumerate_all: every pair of the batch in one launch.  flags: None, one shared row, or an
         [n, stride] uint8 array.  -> n_out[n], scores[n,K], lengths[n,K], pairs[n,K,stride,2] or None, status[n]"""
-        noa = AlnNoa(ENUM_CW if kind == "cw" else ENUM_UCW, int(number_suboptimal), float(np.float32(delta_ratio)), int(user_limit), -1, None, 0)
+        noa = AlnNoa({"cw": ENUM_CW, "ucw": ENUM_UCW, "kscw": ENUM_KSCW}[kind], int(number_suboptimal), float(np.float32(delta_ratio)),
+                     int(user_limit), -1, None, int(k_limit))
         if K is None:
             K = max(int(number_suboptimal), 1) + 2
         fl, fstride = None, 0

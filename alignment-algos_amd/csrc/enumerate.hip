@@ -529,7 +529,9 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
                                        int32_t* lengths, int32_t* pairs, int32_t pair_stride, int32_t* status) {
   if (!b || !noa || !n_out || !scores || !lengths || !status || K <= 0) return ALN_E_ARG;
   if (!b->have_dp || b->have_sub || b->direction != ALN_FWD) return ALN_E_STATE;
-  if (noa->kind == ALN_ENUM_CW && !flags) return ALN_E_ARG;
+  const bool ks = noa->kind == ALN_ENUM_KSCW;
+  if ((noa->kind == ALN_ENUM_CW || ks) && !flags) return ALN_E_ARG;
+  if (noa->kind != ALN_ENUM_CW && noa->kind != ALN_ENUM_UCW && !ks) return ALN_E_ARG;
   if (pairs && pair_stride < b->path_stride) return ALN_E_ARG;
   aln_ctx* ctx = b->ctx;
   ALN_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -538,9 +540,12 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   // every set starts with the pair's Optimal alignment (aa_ali.cpp:83)
   int rc = launch_traceback(b, false);
   if (rc) return rc;
-  const uint32_t user_limit = noa->user_limit ? noa->user_limit : (noa->kind == ALN_ENUM_CW ? 1000000u : 100000u);
+  const uint32_t user_limit = noa->user_limit ? noa->user_limit : (noa->kind == ALN_ENUM_UCW ? 100000u : 1000000u);
   EnumArgs a = {};
   a.kind = noa->kind; a.user_limit = user_limit; a.delta_ratio = noa->delta_ratio; a.first_slot = 1;
+  a.k_limit = ks ? (noa->k_limit ? noa->k_limit : 16u) : 0u;
+  if (a.k_limit > 64u) return ALN_E_ARG;
+  a.cand_cap = (uint32_t)(b->maxQ + b->maxT);
   a.ali_cap = ali_cap_per_pair ? ali_cap_per_pair : 65536u;
   a.node_cap = node_cap_per_pair ? node_cap_per_pair : (1u << 20);
   a.stack_cap = (uint32_t)(b->maxQ + b->maxT + 8);
@@ -549,8 +554,8 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   uint8_t* d_flags = nullptr; int32_t *d_out = nullptr, *d_sel = nullptr, *d_lists = nullptr, *d_lens = nullptr;
   hipEvent_t evs[4] = {nullptr, nullptr, nullptr, nullptr};
   auto cleanup = [&]() {
-    hipFree(a.node_pair); hipFree(a.node_next); hipFree(a.head); hipFree(a.score); hipFree(a.stack); hipFree(d_flags); hipFree(d_out);
-    hipFree(d_sel); hipFree(d_lists); hipFree(d_lens);
+    hipFree(a.node_pair); hipFree(a.node_next); hipFree(a.head); hipFree(a.score); hipFree(a.stack); hipFree(a.uid); hipFree(d_flags);
+    hipFree(d_out); hipFree(d_sel); hipFree(d_lists); hipFree(d_lens);
     for (auto ev : evs) if (ev) hipEventDestroy(ev);
   };
 #define BTRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup(); return ALN_E_HIP; } } while (0)
@@ -558,7 +563,8 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   BTRY(hipMalloc((void**)&a.node_next, (size_t)n * a.node_cap * 4));
   BTRY(hipMalloc((void**)&a.head, (size_t)n * a.ali_cap * 4));
   BTRY(hipMalloc((void**)&a.score, (size_t)n * a.ali_cap * 4));
-  BTRY(hipMalloc((void**)&a.stack, (size_t)n * a.stack_cap * kFrameWords * 4));
+  BTRY(hipMalloc((void**)&a.stack, (size_t)n * a.stack_cap * (ks ? 8 + 4 * a.k_limit : kFrameWords) * 4));
+  if (ks) BTRY(hipMalloc((void**)&a.uid, (size_t)n * a.ali_cap * 4));
   const size_t fl_bytes = flags ? (flags_stride ? (size_t)n * flags_stride : (size_t)b->maxT) : (size_t)b->maxT;
   BTRY(hipMalloc((void**)&d_flags, fl_bytes));
   BTRY(hipMalloc((void**)&d_out, (size_t)n * 16));
@@ -575,9 +581,14 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   const bool tpos = b->gapdev.model != ALN_GAP_AFFINE_CONST;
   for (auto& ev : evs) BTRY(hipEventCreate(&ev));
   BTRY(hipEventRecord(evs[0], ctx->stream));
-  hipLaunchKernelGGL(enumerate_kernel, dim3(n), dim3(64), 0, ctx->stream, b->d_pairs, 0, proto, sub ? b->d_qcodes : nullptr,
-                     sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr, b->d_H, b->d_P,
-                     sub ? nullptr : b->d_S, a);
+  if (ks)
+    hipLaunchKernelGGL(enumerate_ks_kernel, dim3(n), dim3(64), (size_t)a.cand_cap * 8, ctx->stream, b->d_pairs, 0, proto,
+                       sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr,
+                       b->d_H, b->d_P, sub ? nullptr : b->d_S, a);
+  else
+    hipLaunchKernelGGL(enumerate_kernel, dim3(n), dim3(64), 0, ctx->stream, b->d_pairs, 0, proto, sub ? b->d_qcodes : nullptr,
+                       sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr, b->d_H, b->d_P,
+                       sub ? nullptr : b->d_S, a);
   BTRY(hipGetLastError());
   BTRY(hipEventRecord(evs[1], ctx->stream));
   std::vector<int32_t> hout((size_t)n * 4);

@@ -146,6 +146,15 @@ __global__ __launch_bounds__(64) void enumerate_ks_kernel(const PairDesc* __rest
   extern __shared__ float ks_lds[];
   float* csc = ks_lds;                                           // candidate sums
   int* cix = reinterpret_cast<int*>(ks_lds + a.cand_cap);        // candidate indices (position in the reference's scan order)
+  pair += (int)blockIdx.x;                                       // batched launch (aln_batch_enumerate_all): one workgroup per pair,
+  {                                                              // each with its own slice of the pools
+    const size_t bi = blockIdx.x;
+    a.node_pair += bi * a.node_cap; a.node_next += bi * a.node_cap;
+    a.head += bi * a.ali_cap; a.score += bi * a.ali_cap; a.uid += bi * a.ali_cap;
+    a.stack += bi * (size_t)a.stack_cap * (8 + 4 * a.k_limit);
+    a.flags += bi * (size_t)a.flags_stride;
+    a.out += bi * 4;
+  }
   const PairDesc pd = pairs[pair];
   EvalDev e = proto;
   e.Q = pd.Q; e.T = pd.T; e.ld = pd.ld;

@@ -57,8 +57,8 @@ enum aln_dp_algo {
 enum aln_enum_kind {
   ALN_ENUM_CW = 0,              /* ConstrainedNearOptimal, cw.h:68-284 */
   ALN_ENUM_UCW = 1,             /* UnconstrainedNearOptimal, ucw.h:64-236 */
-  ALN_ENUM_KSCW = 2             /* KSConstrainedNearOptimal, kscw.h:109-351 (aln_batch_enumerate only; parity unpinned: the reference
-                                   header does not compile on LP64) */
+  ALN_ENUM_KSCW = 2             /* KSConstrainedNearOptimal, kscw.h:109-351 (parity unpinned: the reference header does not
+                                   compile on LP64) */
 };
 
 enum aln_status {

@@ -192,3 +192,38 @@ def test_kscw_vs_oracle(blosum62):
                 assert g["uid"] == r["uid"], (mode, gi, p, klim, k, g["uid"], r["uid"])
                 assert np.array_equal(g["pairs"], r["pairs"]), (mode, gi, p, klim, k)
         b.close()
+
+
+def test_batched_kscw_matches_single_pair_and_oracle(blosum62):
+    """aln_batch_enumerate_all with ALN_ENUM_KSCW: every pair of a ragged batch in one launch (one workgroup per pair, own
+    pool slices); set size, order, score bits and pair lists against the one-pair entry point and the oracle's restatement."""
+    alpha, table = blosum62
+    lens = [9, 24, 57, 64, 90, 130, 33, 200]
+    pairs = [homolog_pair(66000 + n, ln, sub_rate=0.2, indel=3) for n, ln in enumerate(lens)]
+    maxT = max(len(t) for _, t in pairs) + 2
+    for mode, (gi, ge), nsub, delta, klim in ((1, (11, 1), 40, 0.1, 4), (3, (11, 1), 20, 0.3, 16), (4, (4.73, 0.34), 300, 0.05, 2)):
+        b = aln_amd.Batch(gpu_util.ctx(), [p[0] for p in pairs], [p[1] for p in pairs])
+        b.dp_submatrix(alpha, table, mode, gi, ge)
+        flags = np.zeros((len(pairs), maxT), dtype=np.uint8)
+        for p, (q, t) in enumerate(pairs):
+            flags[p, :len(t) + 2] = orc.make_subopt_regions(len(t) + 2, 2 + p % 5)
+        n_out, scores, lengths, lists, status = b.enumerate_all("kscw", nsub, delta, flags, K=nsub + 2, node_cap=1 << 20, ali_cap=1 << 16,
+                                                                 k_limit=klim)
+        assert (status == 0).all()
+        for p, (q, t) in enumerate(pairs):
+            S = orc.sim_submatrix(q, t, alpha, table)
+            gap = orc.Gap(mode, gi, ge)
+            rc, D0, PQ0, PT0 = orc.dp_build(S, gap)
+            rc2, sc, pl = orc.optimal(D0, PQ0, PT0, mode == 3)
+            s = orc.AliSet()
+            s.push(pl, sc)
+            assert orc.enumerate_ks(D0, PQ0, PT0, S, gap, flags[p, :len(t) + 2], nsub, delta, klim, s) == 0
+            assert n_out[p] == len(s), (mode, p, n_out[p], len(s))
+            one = b.enumerate(p, "kscw", nsub, delta, flags[p, :len(t) + 2], k_limit=klim, max_alignments=nsub + 2)
+            assert len(one) == len(s)
+            for k in range(len(s)):
+                r = s.get(k)
+                assert scores[p, k].view(np.uint32) == r["score"].view(np.uint32), (mode, p, k)
+                assert np.array_equal(lists[p, k, :lengths[p, k]], r["pairs"]), (mode, p, k)
+                assert np.array_equal(one[k]["pairs"], r["pairs"])
+        b.close()
