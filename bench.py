@@ -86,7 +86,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--pairs", type=int, default=1024, help="pairs per GPU (config 2: 1024)")
     ap.add_argument("--length", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
