@@ -60,11 +60,13 @@ int aln_ctx_create(int device_id, void* stream, aln_ctx** out) {
     c->own_stream = true;
   }
   *out = c;
+  ++g_live_contexts;
   return ALN_OK;
 }
 
 void aln_ctx_destroy(aln_ctx* ctx) {
   if (!ctx) return;
+  --g_live_contexts;
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -50,6 +51,10 @@ struct GapDev {
 };
 
 }  // namespace aln
+
+// Contexts alive in this process.  One context = launches follow each other on one stream (the "lone launch" regime, where
+// the tagged kernel's row-alternating wave priority pays); several = the caller overlaps launches of different contexts.
+extern std::atomic<int> g_live_contexts;
 
 struct aln_ctx {
   int device;

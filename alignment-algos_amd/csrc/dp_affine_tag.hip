@@ -28,6 +28,8 @@
 
 #include "aln_internal.h"
 
+std::atomic<int> g_live_contexts{0};   // see aln_internal.h; counted by aln_ctx_create / aln_ctx_destroy
+
 namespace aln {
 
 namespace tag {
@@ -304,8 +306,8 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
   for (int i = 2; i <= Q - 2; ++i) {
     // The SIMD's arbiter favours its older wave: of the 4 pairs of a CU the first finishes after 2.4 ms, the last after
     // 3.3 ms, and the SIMD idles behind the early finishers.  Alternating the user priority row by row (by the parity of
-    // the wave's hardware slot) evens that out: -6 % on a lone launch.  Off by default, because launches that overlap on
-    // two streams (bench.py) fill those gaps better and lose with it (ALN_TAG_ALT_PRIO=1 turns it on).
+    // the wave's hardware slot) evens that out: -3...-6 % on a lone launch.  Launches that overlap on several streams
+    // (bench.py) fill those gaps better and lose with it; launch_dp_affine_tag decides (one context alive -> on).
     if (prm.alt_prio) {
       if ((i ^ hwslot) & 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
     }
@@ -482,7 +484,9 @@ int launch_dp_affine_tag(aln_batch* b) {
   prm.ge = (int)b->gap.gap_extn;
   prm.free_del = b->gapdev.free_del;
   prm.free_ins = b->gapdev.free_ins;
-  { const char* e = getenv("ALN_TAG_ALT_PRIO"); prm.alt_prio = (e && *e == '1') ? 1 : 0; }
+  // row-alternating wave priority: on when this is the only context of the process (launches then follow each other and the
+  // arbiter's favouritism costs ~6 %), off when the caller overlaps launches of several contexts; ALN_TAG_ALT_PRIO=0/1 decides
+  { const char* e = getenv("ALN_TAG_ALT_PRIO"); prm.alt_prio = e ? (*e == '1') : (g_live_contexts.load() <= 1); }
   const int ld = row_stride(b->maxT);
   // variant = waves per pair, groups per lane, consecutive columns a lane owns in a group (ALN_DP_VARIANT="NW,R[,X]")
   int nw = 0, r = 0, x = 4;
