@@ -66,7 +66,11 @@ EXPORTS = [
     "aln_batch_reevaluate", "aln_batch_dp_kernel_name", "aln_batch_dp_sub", "aln_batch_get_cells", "aln_batch_get_sim",
     "aln_batch_get_corner_scores", "aln_batch_optimal", "aln_batch_optimal_enqueue", "aln_batch_optimal_collect", "aln_batch_optimal_subali", "aln_batch_enumerate", "aln_batch_enumerate_all", "aln_batch_last_enum_ms", "aln_identity",
     "aln_gapped_length", "aln_gapped_strings", "aln_hmap2_gap_arrays", "aln_score_all_vs_all", "aln_batch_last_dp_ms", "aln_batch_dp_ms_history", "aln_batch_dp_algorithmic_bytes", "aln_batch_cells",
+    "aln_batch_optimal_strings", "aln_ctx_set_hint", "aln_ctx_get_hint", "aln_batch_dp_contract_bytes", "aln_batch_plane_bytes_per_cell",
+    "aln_deal_units", "aln_comm_unique_id", "aln_comm_create", "aln_ctx_create_multi", "aln_comm_destroy", "aln_comm_n_ranks",
+    "aln_comm_last_error", "aln_gather_scores",
 ]
+COMM_ID_BYTES = 128
 
 _LIB = None
 
@@ -94,7 +98,7 @@ def lib():
         L.aln_batch_dp_kernel_name.restype = C.c_char_p
         L.aln_batch_dp_kernel_name.argtypes = [C.c_void_p]
         L.aln_identity.restype = C.c_float
-        for f in ("aln_batch_device_bytes", "aln_batch_dp_algorithmic_bytes", "aln_batch_cells"):
+        for f in ("aln_batch_device_bytes", "aln_batch_dp_algorithmic_bytes", "aln_batch_dp_contract_bytes", "aln_batch_cells"):
             getattr(L, f).restype = C.c_int64
             getattr(L, f).argtypes = [C.c_void_p]
         L.aln_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
@@ -127,6 +131,19 @@ def lib():
         L.aln_score_all_vs_all.argtypes = [C.c_void_p, C.POINTER(AlnSeqs), C.POINTER(AlnSeqs), C.POINTER(AlnSubmatrix), C.POINTER(AlnGap),
                                            C.c_int32, C.c_int32, _fp]
         L.aln_hmap2_gap_arrays.argtypes = [_fp, C.c_int64, C.c_float, C.c_float, C.c_float, _fp, _fp]
+        L.aln_batch_plane_bytes_per_cell.argtypes = [C.c_void_p]
+        L.aln_batch_optimal_strings.argtypes = [C.c_void_p, _fp, _fp, _ip, C.c_char_p, C.c_char_p, C.c_int32, _ip]
+        L.aln_ctx_set_hint.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        L.aln_ctx_get_hint.argtypes = [C.c_void_p, C.c_char_p, _lp]
+        L.aln_deal_units.argtypes = [_lp, C.c_int64, C.c_int32, _ip, _ip]
+        L.aln_comm_unique_id.argtypes = [C.c_void_p]
+        L.aln_comm_create.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        L.aln_ctx_create_multi.argtypes = [_ip, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        L.aln_comm_destroy.argtypes = [C.c_void_p]
+        L.aln_comm_n_ranks.argtypes = [C.c_void_p]
+        L.aln_comm_last_error.argtypes = [C.c_void_p]
+        L.aln_comm_last_error.restype = C.c_char_p
+        L.aln_gather_scores.argtypes = [C.c_void_p, C.POINTER(_fp), C.POINTER(_ip), _ip, C.c_int32, _fp, C.c_int64]
         _LIB = L
     return _LIB
 
@@ -165,6 +182,30 @@ class Context:
 
     def synchronize(self):
         _check(lib().aln_ctx_synchronize(self.h), self.h)
+
+    def set_hint(self, key, value):
+        """aln_ctx_set_hint: a tuning / kernel-selection switch of this context (never changes a result)."""
+        _check(lib().aln_ctx_set_hint(self.h, key.encode(), int(value)), self.h)
+
+    def get_hint(self, key):
+        v = C.c_int64(0)
+        _check(lib().aln_ctx_get_hint(self.h, key.encode(), C.byref(v)), self.h)
+        return v.value
+
+    def hints(self, **kv):
+        """Context manager: set hints, restore the previous values on exit."""
+        ctx = self
+
+        class _H:
+            def __enter__(self_):
+                self_.old = {k: ctx.get_hint(k) for k in kv}
+                for k, v in kv.items():
+                    ctx.set_hint(k, v)
+
+            def __exit__(self_, *a):
+                for k, v in self_.old.items():
+                    ctx.set_hint(k, v)
+        return _H()
 
     def close(self):
         if self.h:
@@ -345,7 +386,15 @@ class Batch:
         return lib().aln_batch_cells(self.h)
 
     def algorithmic_bytes(self):
+        """bytes one DP launch must write with the chosen plane layout (4, 6 or 8 B per matrix cell)"""
         return lib().aln_batch_dp_algorithmic_bytes(self.h)
+
+    def contract_bytes(self):
+        """SURVEY 8(d)'s figure: 8 B per matrix cell (fp32 score + 32-bit pointer), whatever layout was chosen"""
+        return lib().aln_batch_dp_contract_bytes(self.h)
+
+    def plane_bytes_per_cell(self):
+        return lib().aln_batch_plane_bytes_per_cell(self.h)
 
     def device_bytes(self):
         return lib().aln_batch_device_bytes(self.h)
@@ -440,6 +489,26 @@ class Batch:
         status = np.zeros(self.n, dtype=np.int32)
         _check(lib().aln_batch_optimal_collect(self.h, _f(scores), _i(cnt), _i(status)), self.ctx.h)
         return scores, cnt, status
+
+    def optimal_strings(self, decode=True):
+        """aln_batch_optimal_strings -> scores[n], identity[n], status[n], template lines, query lines (lists of str, or the
+        raw buffers + lengths when decode is False)."""
+        scores = np.empty(self.n, dtype=np.float32)
+        ident = np.zeros(self.n, dtype=np.float32)
+        status = np.zeros(self.n, dtype=np.int32)
+        lengths = np.zeros(self.n, dtype=np.int32)
+        stride = max(sum(self.dims(p)) for p in range(self.n)) + 2 if self.n else 4
+        if not hasattr(self, "_tl") or len(self._tl) < self.n * stride:
+            self._tl = C.create_string_buffer(self.n * stride)
+            self._ql = C.create_string_buffer(self.n * stride)
+        rc = lib().aln_batch_optimal_strings(self.h, _f(scores), _f(ident), _i(status), self._tl, self._ql, stride, _i(lengths))
+        if rc != 0 and rc != E_STARTPAIR:
+            _check(rc, self.ctx.h)
+        if not decode:
+            return scores, ident, status, self._tl, self._ql, lengths, stride
+        tl = [self._tl.raw[p * stride:p * stride + lengths[p]].decode() for p in range(self.n)]
+        ql = [self._ql.raw[p * stride:p * stride + lengths[p]].decode() for p in range(self.n)]
+        return scores, ident, status, tl, ql
 
     def optimal(self, want_pairs=True, subali=False):
         """-> scores[n], list of pair arrays (list order), status[n]"""

@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 
 #include "aln_device.h"
 
@@ -44,7 +45,30 @@ extern "C" {
 
 const char* aln_error_string(int status) { return kErrStr(status); }
 const char* aln_last_error(const aln_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
-int aln_has_gfx950(void) { return 1; }
+// Does THIS shared object carry a gfx950 code object?  hipcc embeds one offload bundle per --offload-arch whose entry id is
+// "hipv4-amdgcn-amd-amdhsa--gfx950": look for that id in the file the function itself was loaded from (works without a GPU).
+int aln_has_gfx950(void) {
+  static int cached = -1;
+  if (cached >= 0) return cached;
+  Dl_info info;
+  if (!dladdr(reinterpret_cast<const void*>(&aln_has_gfx950), &info) || !info.dli_fname) return cached = 0;
+  FILE* f = fopen(info.dli_fname, "rb");
+  if (!f) return cached = 0;
+  static const char kId[] = "hipv4-amdgcn-amd-amdhsa--gfx950";
+  const size_t idn = sizeof kId - 1;
+  std::vector<char> buf(1 << 20);
+  size_t keep = 0, got;
+  int found = 0;
+  while (!found && (got = fread(buf.data() + keep, 1, buf.size() - keep, f)) > 0) {
+    const size_t n = keep + got;
+    for (size_t k = 0; k + idn <= n; ++k)
+      if (buf[k] == 'h' && memcmp(buf.data() + k, kId, idn) == 0) { found = 1; break; }
+    keep = n < idn ? n : idn - 1;
+    memmove(buf.data(), buf.data() + n - keep, keep);
+  }
+  fclose(f);
+  return cached = found;
+}
 
 int aln_ctx_create(int device_id, void* stream, aln_ctx** out) {
   if (!out) return ALN_E_ARG;
@@ -59,14 +83,13 @@ int aln_ctx_create(int device_id, void* stream, aln_ctx** out) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ALN_E_HIP; }
     c->own_stream = true;
   }
+  aln::hints_from_env(&c->hints);
   *out = c;
-  ++g_live_contexts;
   return ALN_OK;
 }
 
 void aln_ctx_destroy(aln_ctx* ctx) {
   if (!ctx) return;
-  --g_live_contexts;
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -154,12 +177,15 @@ void aln_batch_destroy(aln_batch* b) {
 
 int32_t aln_batch_n_pairs(const aln_batch* b) { return b ? b->n_pairs : 0; }
 int64_t aln_batch_cells(const aln_batch* b) { return b ? b->cells : 0; }
-int64_t aln_batch_dp_algorithmic_bytes(const aln_batch* b) {
-  if (!b) return 0;
+static int64_t matrix_cells(const aln_batch* b) {
   int64_t n = 0;
   for (const PairDesc& d : b->h_pairs) n += (int64_t)d.Q * d.T;
-  return n * 8;   // fp32 score + packed pointer per cell
+  return n;
 }
+// score element + pointer element of the layout the last build chose (aln_device.h load_score / load_ptr_word)
+int32_t aln_batch_plane_bytes_per_cell(const aln_batch* b) { return b ? (b->h_mode ? 2 : 4) + (b->ptr_mode ? 2 : 4) : 0; }
+int64_t aln_batch_dp_algorithmic_bytes(const aln_batch* b) { return b ? matrix_cells(b) * aln_batch_plane_bytes_per_cell(b) : 0; }
+int64_t aln_batch_dp_contract_bytes(const aln_batch* b) { return b ? matrix_cells(b) * 8 : 0; }   // fp32 score + packed pointer
 int64_t aln_batch_device_bytes(const aln_batch* b) {
   if (!b) return 0;
   int64_t n = (int64_t)sizeof(PairDesc) * b->n_pairs + b->q_total + b->t_total + (int64_t)sizeof(PairResult) * b->n_pairs;
@@ -294,11 +320,11 @@ int run_dp(aln_batch* b, bool simplane_integral) {
   bool fast = false, tagged = false;
   if (b->algo != ALN_DP_EXACT && !b->have_sub && b->direction == ALN_FWD) {
     fast = fast_path_legal(b, sub ? b->h_table.data() : nullptr, b->alpha_n, &b->gap, simplane_integral);
-    tagged = fast && sub && tag_path_legal(b, b->h_table.data(), b->alpha_n, &b->gap) && !getenv("ALN_NO_TAG_KERNEL");
+    tagged = fast && sub && tag_path_legal(b, b->h_table.data(), b->alpha_n, &b->gap) && ctx->hints.tag_kernel;
   }
   if (b->algo == ALN_DP_FAST && !fast) return ALN_E_NOT_INTEGRAL;
   b->ptr_mode = tagged ? 1 : 0;
-  b->h_mode = (tagged && b->islocal && !getenv("ALN_NO_H16")) ? 1 : 0;   // local scores of the tagged path are integers in [0, 65535]
+  b->h_mode = (tagged && b->islocal && ctx->hints.h16) ? 1 : 0;   // local scores of the tagged path are integers in [0, 65535]
   {
     const int slot = (int)(b->n_builds % aln_batch::kEvRing);
     if (!b->ring0[slot]) { ALN_HIP_CHECK(ctx, hipEventCreate(&b->ring0[slot])); ALN_HIP_CHECK(ctx, hipEventCreate(&b->ring1[slot])); }
@@ -364,13 +390,14 @@ int aln_batch_dp(aln_batch* b, const aln_sim* sim, const aln_gap* gap, int32_t d
   bool integral = false;
   int rc = prepare_dp(b, sim, gap, direction, algo, bug_b4, &integral);
   if (rc) return rc;
+  b->simplane_integral = integral;
   return run_dp(b, integral);
 }
 
 int aln_batch_reevaluate(aln_batch* b) {
   if (!b) return ALN_E_ARG;
   if (!b->have_dp) return ALN_E_STATE;
-  return run_dp(b, false);
+  return run_dp(b, b->simplane_integral);      // the resident similarity planes are the ones the first build proved integral (or not)
 }
 
 int aln_batch_dp_sub(aln_batch* b, const aln_sim* sim, const aln_gap* gap, int32_t direction, const int32_t* bounds) {
@@ -387,6 +414,7 @@ int aln_batch_dp_sub(aln_batch* b, const aln_sim* sim, const aln_gap* gap, int32
   bool integral = false;
   int rc = prepare_dp(b, sim, gap, direction, ALN_DP_EXACT, 0, &integral);
   if (rc) return rc;
+  b->simplane_integral = integral;
   for (int p = 0; p < b->n_pairs; ++p) {
     PairDesc& d = b->h_pairs[p];
     d.q0 = bounds[4 * p]; d.t0 = bounds[4 * p + 1]; d.q1 = bounds[4 * p + 2]; d.t1 = bounds[4 * p + 3];
@@ -579,6 +607,52 @@ int aln_batch_optimal_subali(aln_batch* b, float* scores, int32_t* n, int32_t* p
   int rc = launch_traceback(b, true);
   if (rc) return rc;
   return fetch_paths(b, scores, n, pairs, pair_stride, status, true, true);
+}
+
+// Optimal + assignIdentity + SequenceGaps for every pair of the batch: the strings a driver prints for
+// `AlignmentSet alignments(dpm, optimal); alignments.assignIdentity(); cout << FastaOut(len) << alignments`
+// (aa_ali.cpp:83-92, fastaio.h:51-76, gstrings.h:84-164).  Device: find_max + traceback; then the pair lists come to the host
+// and the gapped lines are built there (host_strings.cpp), pair after pair.
+int aln_batch_optimal_strings(aln_batch* b, float* scores, float* identity, int32_t* status, char* tlines, char* qlines,
+                              int32_t stride, int32_t* lengths) {
+  if (!b || !tlines || !qlines || stride < 1) return ALN_E_ARG;
+  if (!b->have_dp || b->have_sub) return ALN_E_STATE;
+  if (b->n_pairs == 0) return ALN_OK;
+  int rc = launch_traceback(b, false);
+  if (rc) return rc;
+  const int n = b->n_pairs;
+  std::vector<float> sc(n);
+  std::vector<int32_t> cnt(n), st(n), path((size_t)n * b->path_stride * 2);
+  rc = fetch_paths(b, sc.data(), cnt.data(), path.data(), b->path_stride, st.data(), !b->islocal, b->direction == ALN_FWD);
+  if (rc) return rc;
+  int worst = ALN_OK;
+  for (int p = 0; p < n; ++p) {
+    const PairDesc& d = b->h_pairs[p];
+    const char* q = b->q_res.data() + d.q_off;
+    const char* t = b->t_res.data() + d.t_off;
+    const int32_t* pl = path.data() + (size_t)p * b->path_stride * 2;
+    char* tl = tlines + (size_t)p * stride;
+    char* ql = qlines + (size_t)p * stride;
+    tl[0] = ql[0] = 0;
+    if (scores) scores[p] = sc[p];
+    if (status) status[p] = st[p];
+    if (lengths) lengths[p] = 0;
+    if (identity) identity[p] = 0.f;
+    if (st[p] != 0) { if (worst == ALN_OK) worst = st[p]; continue; }
+    aln_alignment a = {};
+    a.score = sc[p]; a.n_pairs = cnt[p]; a.pair_off = 0;
+    if (identity) identity[p] = aln_identity(q, d.Q, t, d.T, pl, cnt[p]);
+    // SequenceGaps needs a list that ends at the tail pair and never repeats a pair (Optimal_Rev's local lists can do both)
+    bool printable = cnt[p] > 0 && pl[2 * (cnt[p] - 1)] == d.Q - 1 && pl[2 * (cnt[p] - 1) + 1] == d.T - 1;
+    for (int k = 1; k < cnt[p] && printable; ++k) if (pl[2 * k] == pl[2 * k - 2] && pl[2 * k + 1] == pl[2 * k - 1]) printable = false;
+    if (!printable) continue;
+    const int len = aln_gapped_length(d.T, &a, 1, pl);
+    if (len >= stride) { worst = ALN_E_OVERFLOW; continue; }
+    const int rs = aln_gapped_strings(q, d.Q, t, d.T, &a, 1, pl, tl, ql, stride);
+    if (rs != ALN_OK) { if (worst == ALN_OK) worst = rs; continue; }
+    if (lengths) lengths[p] = len;
+  }
+  return worst;
 }
 
 // aln_batch_enumerate lives in enumerate.hip

@@ -52,15 +52,31 @@ struct GapDev {
 
 }  // namespace aln
 
-// Contexts alive in this process.  One context = launches follow each other on one stream (the "lone launch" regime, where
-// the tagged kernel's row-alternating wave priority pays); several = the caller overlaps launches of different contexts.
-extern std::atomic<int> g_live_contexts;
+// Tuning / kernel-selection hints of a context (aln_ctx_set_hint).  Defaults come from the environment variables named in
+// aln_hints.hip's table, read ONCE when the context is created — nothing reads the environment at launch time.
+struct aln_hints {
+  int tag_kernel = 1;        // 0: never use the tagged-key kernel (dp_affine_int instead)
+  int h16 = 1;               // 0: keep fp32 score planes in local tagged builds
+  int key16 = 1;             // 0: never use the 16-bit key layout
+  int tag_alt_prio = 1;      // tagged kernel: alternate s_setprio per row by hardware-slot parity (pays on lone launches; a caller that
+                             // overlaps launches of several contexts sets 0)
+  int tag_persistent = 1;    // tagged kernel: persistent workgroups that pull pairs from a queue (0: one workgroup per pair)
+  int dp_nw = 0, dp_r = 0, dp_x = 0;   // force a row-sweep variant (waves per pair, groups per lane, columns per lane and group); 0 = auto
+  int exact_tiles = 1;       // 0: dp_exact_blocked instead of dp_exact_tiled where both apply
+  int exact_literal = 0;     // 1: the literal O(n^3) kernel everywhere
+  int exact_alt_prio = 1;    // tiled exact kernel: priority rotation over the 4 resident waves
+  int score_packed = 1;      // 0: one query per wave in aln_score_all_vs_all
+  int64_t enum_node_cap = 0; // trie nodes of aln_batch_enumerate (0 = default)
+};
+
+struct aln_comm;
 
 struct aln_ctx {
   int device;
   hipStream_t stream;
   bool own_stream;
   std::string last_error;
+  aln_hints hints;
 };
 
 struct aln_batch {
@@ -95,6 +111,7 @@ struct aln_batch {
   aln_gap gap;                                 // host copy (pointers not retained beyond dp call)
   aln::GapDev gapdev;
   bool islocal;
+  bool simplane_integral = false;              // ALN_SIM_MATRIX planes of the last dp were all small integers (kept for reevaluate)
   int32_t ptr_mode;                            // encoding of the P plane words (aln_device.h decode_ptr)
   int32_t h_mode;                              // score plane element type: 0 fp32, 1 uint16 (aln_device.h load_score)
   std::string kernel_name;
@@ -124,6 +141,8 @@ struct aln_batch {
 
 namespace aln {
 
+// aln_hints.hip
+void hints_from_env(aln_hints* h);
 // dp_affine_int.hip
 int launch_dp_affine_int(aln_batch* b, bool use_simplane);
 bool fast_path_legal(const aln_batch* b, const float* table, int n, const aln_gap* gap, bool simplane_integral);

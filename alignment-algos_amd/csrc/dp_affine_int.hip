@@ -410,8 +410,7 @@ int launch_dp_affine_int(aln_batch* b, bool use_simplane) {
   const int ld = row_stride(b->maxT);
   // variant choice: columns covered = 256 * R * NW >= ld.  Prefer several waves per pair (VALU issue needs >= 2 waves
   // per SIMD; one barrier per row is cheap) — overridable for tuning with ALN_DP_VARIANT="NW,R".
-  int nw = 0, r = 0;
-  if (const char* e = getenv("ALN_DP_VARIANT")) sscanf(e, "%d,%d", &nw, &r);
+  int nw = b->ctx->hints.dp_nw, r = b->ctx->hints.dp_r;
   if (nw == 0) {
     if (ld <= 256) { nw = 1; r = 1; }
     else if (ld <= 512) { nw = 2; r = 1; }

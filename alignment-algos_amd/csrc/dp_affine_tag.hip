@@ -28,8 +28,6 @@
 
 #include "aln_internal.h"
 
-std::atomic<int> g_live_contexts{0};   // see aln_internal.h; counted by aln_ctx_create / aln_ctx_destroy
-
 namespace aln {
 
 namespace tag {
@@ -457,7 +455,7 @@ template <int NW, int R, int X>
 static int launch_tag_variant(aln_batch* b, const TagParams& prm) {
   dim3 grid(b->n_pairs), block(64 * NW);
   hipStream_t st = b->ctx->stream;
-  const bool k16 = b->islocal && b->h_mode == 1 && tag_key16_legal(b) && !getenv("ALN_NO_KEY16");
+  const bool k16 = b->islocal && b->h_mode == 1 && tag_key16_legal(b) && b->ctx->hints.key16;
   if (k16)
     hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, true, true, 16, X>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
                        b->d_H, b->d_P, b->d_res, prm);
@@ -484,13 +482,12 @@ int launch_dp_affine_tag(aln_batch* b) {
   prm.ge = (int)b->gap.gap_extn;
   prm.free_del = b->gapdev.free_del;
   prm.free_ins = b->gapdev.free_ins;
-  // row-alternating wave priority: on when this is the only context of the process (launches then follow each other and the
-  // arbiter's favouritism costs ~6 %), off when the caller overlaps launches of several contexts; ALN_TAG_ALT_PRIO=0/1 decides
-  { const char* e = getenv("ALN_TAG_ALT_PRIO"); prm.alt_prio = e ? (*e == '1') : (g_live_contexts.load() <= 1); }
+  // row-alternating wave priority: a per-context hint (aln_ctx_set_hint "tag_alt_prio"): it pays while launches follow each other
+  // on one stream (the arbiter's favouritism costs ~6 %) and loses when the caller overlaps launches of several contexts
+  prm.alt_prio = b->ctx->hints.tag_alt_prio;
   const int ld = row_stride(b->maxT);
   // variant = waves per pair, groups per lane, consecutive columns a lane owns in a group (ALN_DP_VARIANT="NW,R[,X]")
-  int nw = 0, r = 0, x = 4;
-  if (const char* e = getenv("ALN_DP_VARIANT")) sscanf(e, "%d,%d,%d", &nw, &r, &x);
+  int nw = b->ctx->hints.dp_nw, r = b->ctx->hints.dp_r, x = b->ctx->hints.dp_x ? b->ctx->hints.dp_x : 4;
   if (nw == 0) {
     if (ld <= 256) { nw = 1; r = 1; }
     else if (ld <= 512) { nw = 2; r = 1; }

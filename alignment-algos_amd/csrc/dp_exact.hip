@@ -126,7 +126,7 @@ int launch_dp_exact(aln_batch* b) {
   aln_ctx* ctx = b->ctx;
   // same results, restructured scans (dp_exact_blocked.hip); this literal kernel stays for templates beyond 4096 columns
   // and for the table gap model
-  if (dp_exact_blocked_legal(b) && !getenv("ALN_EXACT_LITERAL")) return launch_dp_exact_blocked(b);
+  if (dp_exact_blocked_legal(b) && !ctx->hints.exact_literal) return launch_dp_exact_blocked(b);
   // untouched cells read score 0 / pointer (-1,-1) (dpmatrix.cpp:17-25): the kernel only writes computed cells
   ALN_HIP_CHECK(ctx, hipMemsetAsync(b->d_H, 0, (size_t)b->plane_elems * 4, ctx->stream));
   ALN_HIP_CHECK(ctx, hipMemsetAsync(b->d_P, 0xFF, (size_t)b->plane_elems * 4, ctx->stream));

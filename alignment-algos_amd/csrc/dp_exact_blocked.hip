@@ -888,7 +888,7 @@ int launch_dp_exact_blocked(aln_batch* b) {
   for (const PairDesc& d : b->h_pairs) { const int nT = d.t1 - d.t0; if (nT - 1 > mx) mx = nT - 1; }
   const int ns = mx <= 256 ? 1 : mx <= 512 ? 2 : mx <= 1024 ? 4 : 8;
   // templates wider than two tiles: the tiled kernel shares the far-left deletion scans between 16 rows
-  const bool tiled = mx > 2 * kTW && (!getenv("ALN_EXACT_NO_TILES") || mx > 8 * kTW);   // the slot kernel ends at 8 x 256 columns
+  const bool tiled = mx > 2 * kTW && (ctx->hints.exact_tiles || mx > 8 * kTW);   // the slot kernel ends at 8 x 256 columns
   const int ptt = (mx + 1 <= 4 * kTW ? 4 : mx + 1 <= 8 * kTW ? 8 : mx + 1 <= 12 * kTW ? 12 : 16) * kTW + kBPad;          // row pitch of the scratch rows: a compile-time constant of the kernel
   const size_t need = tiled ? (size_t)(6 * kBR + kTRing + 2) * ptt * (size_t)b->n_pairs : blocked_scratch_floats(ns) * (size_t)b->n_pairs;
   if (b->xscratch_floats < need) {
@@ -911,8 +911,7 @@ int launch_dp_exact_blocked(aln_batch* b) {
   if (tiled) {
     const size_t lds = ((size_t)2 * ptt + 2 * kTLoc) * sizeof(float);
     const int rev = (int)(b->direction == ALN_REV);
-    const char* ape = getenv("ALN_EXACT_ALT_PRIO");
-    const int alt_prio = (ape && *ape == '0') ? 0 : 1;   // on unless ALN_EXACT_ALT_PRIO=0
+    const int alt_prio = ctx->hints.exact_alt_prio;      // aln_ctx_set_hint "exact_alt_prio"
 #define ALN_TLAUNCH(PTC, TP, LC)                                                                                                 \
     hipLaunchKernelGGL((dp_exact_tiled_kernel<PTC, TP, LC>), dim3(b->n_pairs), dim3(kTW), lds, ctx->stream, b->d_pairs, proto,     \
                        sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr,                        \

@@ -323,6 +323,12 @@ struct SortKey {
   float score; int32_t idx;
   bool operator<(const SortKey& o) const { return score > o.score; }   // alignment.h:104-105 "higher score first"
 };
+// NOaliParams::user_limit when the caller leaves it 0: the enumerators' own hard-coded / default limits — cw.h:76 (1000000),
+// ucw.h:72 (100000), kscw.h:172 via NOaliParams::default_user_limit (noalib.cpp:19-20: 100000).  One rule for both entry points.
+uint32_t default_user_limit(const aln_noa* noa) {
+  if (noa->user_limit) return noa->user_limit;
+  return noa->kind == ALN_ENUM_CW ? 1000000u : 100000u;
+}
 }  // namespace
 
 extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* noa, const uint8_t* flags, aln_alignment* out,
@@ -352,7 +358,7 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
     if (res[pair].status != 0) return res[pair].status;
   }
 
-  const uint32_t user_limit = noa->user_limit ? noa->user_limit : (noa->kind == ALN_ENUM_CW ? 1000000u : 100000u);
+  const uint32_t user_limit = default_user_limit(noa);
   EnumArgs a = {};
   a.kind = noa->kind;
   a.user_limit = user_limit;
@@ -363,7 +369,7 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   a.cand_cap = (uint32_t)(d.Q + d.T);
   a.ali_cap = user_limit + 65536u + (uint32_t)n_ex;
   a.node_cap = 48u << 20;
-  if (const char* env = getenv("ALN_ENUM_NODE_CAP")) a.node_cap = (uint32_t)strtoul(env, nullptr, 10);
+  if (ctx->hints.enum_node_cap > 0) a.node_cap = (uint32_t)ctx->hints.enum_node_cap;
   a.stack_cap = (uint32_t)(d.Q + d.T + 8);
   uint8_t* d_flags = nullptr; int32_t* d_out = nullptr;
   auto cleanup = [&]() {
@@ -540,7 +546,7 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   // every set starts with the pair's Optimal alignment (aa_ali.cpp:83)
   int rc = launch_traceback(b, false);
   if (rc) return rc;
-  const uint32_t user_limit = noa->user_limit ? noa->user_limit : (noa->kind == ALN_ENUM_UCW ? 100000u : 1000000u);
+  const uint32_t user_limit = default_user_limit(noa);
   EnumArgs a = {};
   a.kind = noa->kind; a.user_limit = user_limit; a.delta_ratio = noa->delta_ratio; a.first_slot = 1;
   a.k_limit = ks ? (noa->k_limit ? noa->k_limit : 16u) : 0u;

@@ -413,21 +413,29 @@ extern "C" int aln_score_all_vs_all(aln_ctx* ctx, const aln_seqs* queries, const
   // packed 16-bit lanes (two queries per wave) when every intermediate provably fits: best local score <= maxs * min(Q,T),
   // A keys add ge * column, the "minus infinity" -12000 must stay below every real candidate and clear of wrap-around
   const double L = (double)std::max(maxQ, maxT), best = maxs * (double)std::min(maxQ, maxT);
-  const bool packed = best + ge * L + maxs < 30000.0 && ge * L + gi + maxs < 8000.0 && maxs < 2048.0 && !getenv("ALN_SCORE_NO_PACKED");
+  const bool packed = best + ge * L + maxs < 30000.0 && ge * L + gi + maxs < 8000.0 && maxs < 2048.0 && ctx->hints.score_packed;
   const dim3 block(64);
-  // blockIdx.y is limited to 65535: walk the query rows in slabs
-  for (int r0 = 0; r0 < rows; r0 += 32768) {
-    const int nr = std::min(32768, rows - r0);
-    if (packed) {       // pair queries of similar length: a wave runs to the longer one's last row
-      std::vector<int32_t> qo(nr);
+  // blockIdx.y is limited to 65535: walk the query rows in slabs.  The packed kernel pairs queries of similar length (a wave
+  // runs to the longer one's last row): every slab's length order goes to the device ONCE, before the first launch, into its own
+  // region of dqsel (slab starting at row r0 -> dqsel + r0), so no launch can see another slab's order (the kernels run
+  // asynchronously on ctx->stream) and the host vector lives until the final synchronisation.
+  std::vector<int32_t> qo_all;
+  if (packed) {
+    qo_all.resize((size_t)rows);
+    for (int r0 = 0; r0 < rows; r0 += 32768) {
+      const int nr = std::min(32768, rows - r0);
+      int32_t* qo = qo_all.data() + r0;
       for (int k = 0; k < nr; ++k) qo[k] = k;
-      std::stable_sort(qo.begin(), qo.end(), [&](int32_t x, int32_t y) {
+      std::stable_sort(qo, qo + nr, [&](int32_t x, int32_t y) {
         return queries->offsets[q_begin + r0 + x + 1] - queries->offsets[q_begin + r0 + x] <
                queries->offsets[q_begin + r0 + y + 1] - queries->offsets[q_begin + r0 + y];
       });
-      if (!dqsel) STRY(hipMalloc((void**)&dqsel, (size_t)std::min(rows, 32768) * 4));
-      STRY(hipMemcpy(dqsel, qo.data(), (size_t)nr * 4, hipMemcpyHostToDevice));   // synchronous: qo dies at the end of this scope
     }
+    STRY(hipMalloc((void**)&dqsel, (size_t)rows * 4));
+    STRY(hipMemcpyAsync(dqsel, qo_all.data(), (size_t)rows * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  for (int r0 = 0; r0 < rows; r0 += 32768) {
+    const int nr = std::min(32768, rows - r0);
     for (int r = 1; r <= 8; ++r) {
       const int nc = cls_begin[r + 1] - cls_begin[r];
       if (nc == 0) continue;
@@ -435,7 +443,7 @@ extern "C" int aln_score_all_vs_all(aln_ctx* ctx, const aln_seqs* queries, const
       s.q_begin = q_begin + r0;
       s.scores = dsc + (size_t)r0 * n_t;
       s.tsel = dsel + cls_begin[r];
-      s.qsel = dqsel;
+      s.qsel = dqsel ? dqsel + r0 : nullptr;
       if (packed) {
         const dim3 grid(nc, (nr + 1) / 2);             // two query rows per wave
         switch (r) {

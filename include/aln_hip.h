@@ -168,8 +168,21 @@ void aln_ctx_destroy(aln_ctx* ctx);
 const char* aln_error_string(int status);
 const char* aln_last_error(const aln_ctx* ctx);
 int aln_ctx_synchronize(aln_ctx* ctx);
-/* 1 if libalnhip.so carries gfx950 code objects (always, or the library does not load). */
+/* 1 if the shared object this function lives in carries a gfx950 code object (the offload-bundle id
+ * "hipv4-amdgcn-amd-amdhsa--gfx950" is looked up in the file itself; needs no GPU), else 0. */
 int aln_has_gfx950(void);
+/* Tuning / kernel-selection hints of ONE context.  A context reads its defaults from the environment once, when it is created
+ * (ALN_NO_TAG_KERNEL, ALN_NO_H16, ALN_NO_KEY16, ALN_TAG_ALT_PRIO, ALN_TAG_PERSISTENT, ALN_DP_VARIANT="NW,R[,X]", ALN_EXACT_NO_TILES,
+ * ALN_EXACT_LITERAL, ALN_EXACT_ALT_PRIO, ALN_SCORE_NO_PACKED, ALN_ENUM_NODE_CAP); launches never read the environment.  Keys:
+ *   "tag_kernel" "h16" "key16"     1/0: tagged-key kernel / uint16 score plane / 16-bit key layout allowed (results identical)
+ *   "tag_alt_prio"                  1/0: row-alternating wave priority in the tagged kernel (a scheduling hint; pays when launches
+ *                                   follow each other on one stream, loses when launches of several contexts overlap)
+ *   "tag_persistent"                1/0: persistent workgroups pulling pairs from a queue / one workgroup per pair
+ *   "dp_variant_nw" "dp_variant_r" "dp_variant_x"   force a row-sweep instantiation (0 = automatic)
+ *   "exact_tiles" "exact_literal" "exact_alt_prio" "score_packed" "enum_node_cap"
+ * Unknown key -> ALN_E_ARG.  No hint changes any result. */
+int aln_ctx_set_hint(aln_ctx* ctx, const char* key, int64_t value);
+int aln_ctx_get_hint(const aln_ctx* ctx, const char* key, int64_t* value);
 
 /* ---- batch = many DPMatrix objects resident in HBM -------------------------------------- */
 /* Replaces N x `DPMatrix(query, templ, ...)` construction up to initMtxMem (dpmatrix.h:250-259):
@@ -217,6 +230,14 @@ int aln_batch_optimal(aln_batch* b, float* scores, int32_t* n, int32_t* pairs, i
  * overlaps the host's launch and copy latency of one step with the kernels of the next (bench.py). */
 int aln_batch_optimal_enqueue(aln_batch* b);
 int aln_batch_optimal_collect(aln_batch* b, float* scores, int32_t* n, int32_t* status);
+/* Optimal + AlignmentSet::assignIdentity + SequenceGaps for every pair: what a driver prints for
+ * `AlignmentSet as(dpm, optimal); as.assignIdentity(); cout << FastaOut(len) << as` (aa_ali.cpp:83-92, fastaio.h:51-76,
+ * gstrings.h:84-164), without the FASTA framing.  Device: find_max + traceback; the pair lists are copied to the host and the
+ * gapped lines built there.  tlines / qlines: n_pairs x stride chars, NUL-terminated (stride > T + Q covers any alignment);
+ * lengths[p] = line length (0: status[p] != 0, or a list SequenceGaps cannot print).  scores/identity/status/lengths may be NULL.
+ * This is the end-to-end readout of config 2 (pair lists D2H + strings); aln_batch_optimal_enqueue/_collect is the score-only one. */
+int aln_batch_optimal_strings(aln_batch* b, float* scores, float* identity, int32_t* status, char* tlines, char* qlines,
+                              int32_t stride, int32_t* lengths);
 /* Optimal_Subali::enumerate (optimal_subali.h:60-84) on the rectangles of the last aln_batch_dp_sub. */
 int aln_batch_optimal_subali(aln_batch* b, float* scores, int32_t* n, int32_t* pairs,
                              int32_t pair_stride, int32_t* status);
@@ -256,6 +277,31 @@ int aln_batch_last_enum_ms(aln_batch* b, float* search_ms, float* unroll_ms);
 int aln_score_all_vs_all(aln_ctx* ctx, const aln_seqs* queries, const aln_seqs* templates, const aln_submatrix* sub,
                          const aln_gap* gap, int32_t q_begin, int32_t q_end, float* scores);
 
+/* ---- multi-GPU: a length-sorted deal of independent units + ONE collective (RCCL all-gather of scores) ----------- */
+/* The reference is one thread, one DPMatrix at a time; pairs are independent (dpmatrix.h:104-111), so ranks own disjoint pair
+ * lists and the only exchange is the final gather of the per-pair scores (BASELINE north_star). */
+typedef struct aln_comm aln_comm;
+#define ALN_COMM_ID_BYTES 128   /* sizeof(ncclUniqueId) */
+/* Length-sorted deal: units sorted by work[u] (= Q*T of a pair, or the residues of a query row) descending, ties by index, dealt
+ * over n_ranks in boustrophedon order (0..n-1, n-1..0, ...).  owner[u] = rank; slot[u] (may be NULL) = position of u in that
+ * rank's local list, which keeps the sorted order (long units first).  Host arithmetic only. */
+int aln_deal_units(const int64_t* work, int64_t n_units, int32_t n_ranks, int32_t* owner, int32_t* slot);
+/* One process per GPU: rank 0 obtains an id, ships its ALN_COMM_ID_BYTES bytes to the other processes by the job's own
+ * transport, and every process calls aln_comm_create(&its_ctx, 1, id, n_ranks, its_rank, ...).
+ * One process driving n GPUs: aln_comm_create(ctxs, n, NULL, n, 0, ...) — or aln_ctx_create_multi, which also makes the contexts.
+ * librccl.so is dlopen()ed on first use.  Collective calls run on each context's stream. */
+int aln_comm_unique_id(void* id_out);
+int aln_comm_create(aln_ctx* const* ctxs, int32_t n_local, const void* id, int32_t n_ranks, int32_t first_rank, aln_comm** out);
+int aln_ctx_create_multi(const int32_t* device_ids, int32_t n, aln_ctx** ctxs_out, aln_comm** comm_out);
+void aln_comm_destroy(aln_comm* comm);
+int32_t aln_comm_n_ranks(const aln_comm* comm);
+const char* aln_comm_last_error(const aln_comm* comm);
+/* All ranks call it together.  Local rank k of this process contributes n_local[k] (<= n_max, the same n_max on every rank)
+ * scores; global_index[k][e] is the position of local score e in the job's pair list.  On return global_out[0..n_total) holds
+ * every contributed score on every rank.  One ncclAllGather of (index, score) records over xGMI. */
+int aln_gather_scores(aln_comm* comm, const float* const* local_scores, const int32_t* const* global_index,
+                      const int32_t* n_local, int32_t n_max, float* global_out, int64_t n_total);
+
 /* ---- host-side helpers with no device work (alignment.h / gstrings.h) -------------------- */
 /* AlignedPairList::calcIdentity (alignment.h:856-865). qstr/tstr include sentinels. */
 float aln_identity(const char* qstr, int32_t Q, const char* tstr, int32_t T,
@@ -281,8 +327,13 @@ int aln_batch_last_dp_ms(aln_batch* b, float* ms);
 /* The same for up to max_n of the latest builds (ms[0] = the latest; the library keeps 64 event pairs), so that a pipelined
  * caller can read the kernel times after its loop instead of synchronising inside it.  Returns how many it wrote, -1 on error. */
 int aln_batch_dp_ms_history(aln_batch* b, float* ms, int32_t max_n);
-/* algorithmic bytes per DP launch: 8 B per cell (fp32 score + packed pointer), SURVEY.md §8(d) */
+/* Bytes one DP launch MUST write to HBM with the plane layout the last aln_batch_dp chose: per cell of the Q x T matrices
+ * the score element (fp32, or uint16 in local tagged builds) + the pointer element (32-bit, or 16-bit tagged words):
+ * 8, 6 or 4 B/cell.  This is what a roofline fraction is computed from.  _contract_bytes is SURVEY.md 8(d)'s figure for the
+ * reference's layout, 8 B per cell (fp32 score + 32-bit packed pointer), whatever was chosen; _plane_bytes_per_cell the factor. */
 int64_t aln_batch_dp_algorithmic_bytes(const aln_batch* b);
+int64_t aln_batch_dp_contract_bytes(const aln_batch* b);
+int32_t aln_batch_plane_bytes_per_cell(const aln_batch* b);
 int64_t aln_batch_cells(const aln_batch* b);      /* sum over pairs of |q|*|t| = (Q-2)(T-2) */
 
 #ifdef __cplusplus

@@ -17,6 +17,8 @@
 //   aa <blosum> <align_t> <gi> <ge> <fwd|rev> <query> <templ> [dump] [opt] [cw N delta flags] [ucw N delta]
 //   sub <blosum> <align_t> <gi> <ge> <fwd|rev> <query> <templ> q1 t1 q2 t2   (7-arg ctor + Optimal_Subali)
 //   time <blosum> <align_t> <gi> <ge> <len> <seed> <npairs>    (times the DPMatrix ctor)
+//   block <blosum> <align_t> <gi> <ge> <seqfile> r0 r1 c0 c1   (score Optimal reports for every (row, col) of a sequence set)
+// extra ops of `aa`: bin <path> (planes as raw little-endian int32: Q T, H bits, PQ, PT — for full-size sha256 goldens)
 
 #include <cstdio>
 #include <cstdlib>
@@ -26,6 +28,8 @@
 #include <sstream>
 #include <iostream>
 #include <chrono>
+#include <fstream>
+#include <vector>
 
 #include "aa_seq.h"
 #include "aasubalib.h"
@@ -75,6 +79,24 @@ static void dump_matrix(const AADpm& dpm) {
   printf("\nS");
   for (int i = 0; i < Q; ++i) for (int j = 0; j < T; ++j) printf(" %08x", fbits(dpm.getSim(i, j)));
   printf("\n");
+}
+
+static void dump_bin(const AADpm& dpm, const char* path) {
+  int Q = dpm.getQuerySize(), T = dpm.getTemplateSize();
+  FILE* f = fopen(path, "wb");
+  if (!f) { fprintf(stderr, "cannot write %s\n", path); exit(2); }
+  int hdr[2] = {Q, T};
+  fwrite(hdr, 4, 2, f);
+  std::vector<int> row(T);
+  for (int pl = 0; pl < 3; ++pl)
+    for (int i = 0; i < Q; ++i) {
+      for (int j = 0; j < T; ++j) {
+        const DPCell* c = dpm.getCell(i, j);
+        row[j] = pl == 0 ? (int)fbits(c->score) : pl == 1 ? c->prev_query_idx : c->prev_template_idx;
+      }
+      fwrite(row.data(), 4, T, f);
+    }
+  fclose(f);
 }
 
 static void dump_set(const char* tag, AASet& as) {
@@ -150,6 +172,34 @@ int main(int argc, char** argv) {
       printf("TIME %.6f CELLS %.0f\n", total, cells);
       return 0;
     }
+    if (cmd == "block") {
+      BlosumMatrix blosum(argv[2]);
+      AliParams p;
+      p.align_type = (align_t)atoi(argv[3]);
+      p.gap_init_penalty = (float)atof(argv[4]);
+      p.gap_extn_penalty = (float)atof(argv[5]);
+      std::ifstream in(argv[6]);
+      std::vector<std::string> seqs;
+      std::string line;
+      while (std::getline(in, line)) seqs.push_back(line);   // an empty line is an empty sequence
+      int r0 = atoi(argv[7]), r1 = atoi(argv[8]), c0 = atoi(argv[9]), c1 = atoi(argv[10]);
+      AAEval ev(p, blosum);
+      for (int r = r0; r < r1; ++r) {
+        printf("ROW %d", r);
+        for (int c = c0; c < c1; ++c) {
+          AASequence q, t;
+          fill_seq(q, "q", seqs[r]);
+          fill_seq(t, "t", seqs[c]);
+          AADpm dpm(q, t, ev, fwd, p.align_type);
+          Optimal<AASequence, AASequence, AAEval> opt(p.align_type);
+          AASet as(dpm, opt);
+          printf(" %08x", fbits(as[0].score));
+        }
+        printf("\n");
+        fflush(stdout);
+      }
+      return 0;
+    }
     if (cmd != "aa" && cmd != "sub") { fprintf(stderr, "unknown cmd\n"); return 2; }
     BlosumMatrix blosum(argv[2]);
     AliParams p;
@@ -182,6 +232,7 @@ int main(int argc, char** argv) {
     for (; a < argc; ++a) {
       std::string op = argv[a];
       if (op == "dump") dump_matrix(dpm);
+      else if (op == "bin") dump_bin(dpm, argv[++a]);
       else if (op == "ctime") printf("CTIME %.6f\n", std::chrono::duration<double>(tc1 - tc0).count());
       else if (op == "corner") {
         printf("CORNER %08x %08x\n", fbits(dpm.getCell(dpm.getQuerySize() - 1, dpm.getTemplateSize() - 1)->score),

@@ -140,10 +140,26 @@ int main() {
     DPMatrix<ProfSequence, ProfSequence, ProfEval> dpm(q, t, ev, dir == 2 ? rev : fwd, p.align_type);
     printf("TGI"); for (int j = 0; j < T; ++j) printf(" %08x", fbits(t[j]->gap_init())); printf("\n");
     printf("TGE"); for (int j = 0; j < T; ++j) printf(" %08x", fbits(t[j]->gap_extn())); printf("\n");
+    if (const char* path = getenv("REF_PROFILE_BIN")) {   // full-size goldens: raw int32 planes Q T, S bits, H bits, PQ, PT
+      FILE* f = fopen(path, "wb");
+      if (!f) return 4;
+      int hdr[2] = {Q, T};
+      fwrite(hdr, 4, 2, f);
+      std::vector<int> row(T);
+      for (int pl = 0; pl < 4; ++pl)
+        for (int i = 0; i < Q; ++i) {
+          for (int j = 0; j < T; ++j)
+            row[j] = pl == 0 ? (int)fbits(dpm.getSim(i, j)) : pl == 1 ? (int)fbits(dpm.getCell(i, j)->score)
+                   : pl == 2 ? dpm.getCell(i, j)->prev_query_idx : dpm.getCell(i, j)->prev_template_idx;
+          fwrite(row.data(), 4, T, f);
+        }
+      fclose(f);
+    } else {
     printf("S"); for (int i = 0; i < Q; ++i) for (int j = 0; j < T; ++j) printf(" %08x", fbits(dpm.getSim(i, j))); printf("\n");
     printf("H"); for (int i = 0; i < Q; ++i) for (int j = 0; j < T; ++j) printf(" %08x", fbits(dpm.getCell(i, j)->score)); printf("\n");
     printf("PQ"); for (int i = 0; i < Q; ++i) for (int j = 0; j < T; ++j) printf(" %d", dpm.getCell(i, j)->prev_query_idx); printf("\n");
     printf("PT"); for (int i = 0; i < Q; ++i) for (int j = 0; j < T; ++j) printf(" %d", dpm.getCell(i, j)->prev_template_idx); printf("\n");
+    }
     if (dir != 2) {
       Optimal<ProfSequence, ProfSequence, ProfEval> opt(p.align_type);
       AlignmentSet<ProfSequence, ProfSequence, ProfEval> as(dpm, opt);

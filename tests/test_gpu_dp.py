@@ -217,14 +217,12 @@ def test_random_batch_vs_oracle(mode, blosum62):
 
 @pytest.mark.parametrize("kernel", ["tag", "int"])
 @pytest.mark.parametrize("variant", ["1,2", "1,8", "2,1", "2,4", "4,1", "4,2", "8,1", "1,4,8", "2,1,8", "2,2,8", "4,1,8"])
-def test_kernel_variants_agree(variant, kernel, blosum62, monkeypatch):
+def test_kernel_variants_agree(variant, kernel, blosum62):
     """Every (waves per pair, groups per lane) instantiation of both row-sweep kernels (tagged keys, Q,T <= 2048;
     plain int32 with explicit arg-max, up to 8192) gives the oracle's planes."""
     alpha, table = blosum62
-    monkeypatch.setenv("ALN_DP_VARIANT", variant)
-    if kernel == "int":
-        monkeypatch.setenv("ALN_NO_TAG_KERNEL", "1")
     nw, r, xc = ([int(x) for x in variant.split(",")] + [4])[:3]
+    hints = {"dp_variant_nw": nw, "dp_variant_r": r, "dp_variant_x": xc, "tag_kernel": 0 if kernel == "int" else 1}
     if kernel == "int" and xc != 4:
         pytest.skip("8 columns per lane and group exist in the tagged kernel only")
     cap = 64 * xc * nw * r - 2
@@ -239,7 +237,8 @@ def test_kernel_variants_agree(variant, kernel, blosum62, monkeypatch):
         ts.append(t)
     for mode in (3, 1):
         b = aln_amd.Batch(gpu_util.ctx(), qs, ts)
-        b.dp_submatrix(alpha, table, mode, 11, 1, aln_amd.FWD, aln_amd.DP_FAST)
+        with gpu_util.ctx().hints(**hints):
+            b.dp_submatrix(alpha, table, mode, 11, 1, aln_amd.FWD, aln_amd.DP_FAST)
         assert "NW=%d,R=%d" % (nw, r) in b.kernel_name() and ("dp_affine_%s" % kernel) in b.kernel_name()
         assert ("X=8" in b.kernel_name()) == (xc == 8)
         for p, (q, t) in enumerate(zip(qs, ts)):
@@ -342,16 +341,13 @@ def test_full_size_three_kernels_agree(blosum62):
     """BASELINE config-2/3 sizes (2000 x 2000): the tagged O(n^2) kernel, the int O(n^2) kernel and the exact-order O(n^3)
     kernel are three independent programmes for the same recurrence; on integer gaps their score and pointer planes must
     be identical cell for cell (the O(n^3) oracle is too slow here; it pins each of them at smaller sizes)."""
-    import os
     alpha, table = blosum62
     pr = [homolog_pair(1001, 2000), random_pair(1002, 2000), homolog_pair(1003, 1990)]
     qs, ts = [p[0] for p in pr], [p[1] for p in pr]
     for mode in (aln_amd.LOCAL, aln_amd.GLOBAL):
         planes = {}
-        for name, algo, env in (("tag", aln_amd.DP_FAST, None), ("int", aln_amd.DP_FAST, "ALN_NO_TAG_KERNEL"), ("exact", aln_amd.DP_EXACT, None)):
-            if env:
-                os.environ[env] = "1"
-            try:
+        for name, algo, hints in (("tag", aln_amd.DP_FAST, {}), ("int", aln_amd.DP_FAST, {"tag_kernel": 0}), ("exact", aln_amd.DP_EXACT, {})):
+            with gpu_util.ctx().hints(**hints):
                 b = aln_amd.Batch(gpu_util.ctx(), qs, ts)
                 b.dp_submatrix(alpha, table, mode, 11, 1, aln_amd.FWD, algo)
                 kn = b.kernel_name()
@@ -360,9 +356,6 @@ def test_full_size_three_kernels_agree(blosum62):
                 sc, lists, status = b.optimal()
                 planes[name + "_opt"] = (sc, lists)
                 b.close()
-            finally:
-                if env:
-                    del os.environ[env]
         for other in ("int", "exact"):
             for p in range(len(pr)):
                 for a, c in zip(planes["tag"][p], planes[other][p]):
@@ -622,16 +615,16 @@ def test_optimal_enqueue_collect(blosum62):
         b.close()
 
 
-def test_row_alternating_priority_is_invisible(blosum62, monkeypatch):
-    """ALN_TAG_ALT_PRIO=1 (s_setprio alternating per row, a scheduling hint of the tagged kernel) changes no cell."""
+def test_row_alternating_priority_is_invisible(blosum62):
+    """The context hint "tag_alt_prio" (s_setprio alternating per row, a scheduling hint of the tagged kernel) changes no cell."""
     alpha, table = blosum62
     pairs = [homolog_pair(77000 + n, ln) for n, ln in enumerate((1500, 1100, 700))] + [random_pair(77100, 1990, 1800)]
     qs, ts = [p[0] for p in pairs], [p[1] for p in pairs]
     planes = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("ALN_TAG_ALT_PRIO", flag)
+    for flag in (0, 1):
         b = aln_amd.Batch(gpu_util.ctx(), qs, ts)
-        b.dp_submatrix(alpha, table, 3, 11, 1, aln_amd.FWD, aln_amd.DP_FAST)
+        with gpu_util.ctx().hints(tag_alt_prio=flag):
+            b.dp_submatrix(alpha, table, 3, 11, 1, aln_amd.FWD, aln_amd.DP_FAST)
         assert "dp_affine_tag" in b.kernel_name() and "NW=2" in b.kernel_name()
         sc, lists, st = b.optimal()
         planes.append([b.get_cells(p) for p in range(len(qs))] + [sc, lists])
@@ -679,3 +672,23 @@ def test_two_contexts_on_two_streams_overlap(blosum62):
         b.close()
     for c in ctxs:
         c.close()
+
+
+def test_optimal_strings_equal_the_reference(blosum62):
+    """aln_batch_optimal_strings (traceback + pair lists to the host + SequenceGaps + calcIdentity for every pair of a batch)
+    against the reference's OPT sets: template line, query line, identity, score."""
+    alpha, table = blosum62
+    for mode, gi, ge in ((3, 11, 1), (1, 11, 1), (4, 4.73, 0.34)):
+        cs = [c for c in goldens.cases() if c["dir"] == "fwd" and c["mode"] == mode and c["gi"] == gi and "OPT" in c.get("sets", {})
+              and "tstr" in c["sets"]["OPT"] and "throw" not in c and c["name"].split("_")[0] not in ("aaa",)][:40]
+        assert len(cs) >= 5
+        b = aln_amd.Batch(gpu_util.ctx(), [c["q"] for c in cs], [c["t"] for c in cs])
+        b.dp_submatrix(alpha, table, mode, gi, ge)
+        scores, ident, status, tl, ql = b.optimal_strings()
+        for k, c in enumerate(cs):
+            ref = c["sets"]["OPT"]
+            assert status[k] == 0, c["name"]
+            assert goldens.f32bits(scores[k]) == ref["alis"][0]["score"], c["name"]
+            assert goldens.f32bits(ident[k]) == ref["alis"][0]["identity"], c["name"]
+            assert tl[k] == ref["tstr"] and ql[k] == ref["alis"][0]["qstr"], c["name"]
+        b.close()

@@ -69,12 +69,8 @@ def test_full_size_exact_kernels_agree():
     """BASELINE config-3 size (2000 x 2000 profiles, Hmap2Eval on the device, min(t[t1],t[t2]) gaps): the tiled kernel (shared
     far-left deletion scans), the slot kernel (per-row scans) and — on a 700-column pair, where it finishes in seconds — the
     literal O(n^3) kernel are independent programmes for the same arithmetic; planes, scores and paths must be identical."""
-    import os
-
-    def run(qps, tps, env):
-        for k in env:
-            os.environ[k] = "1"
-        try:
+    def run(qps, tps, hints):
+        with gpu_util.ctx().hints(**hints):
             qpool = {k: np.concatenate([p[k] for p in qps]) for k in ("aa", "sse", "conf")}
             tpool = {k: np.concatenate([p[k] for p in tps]) for k in ("aa", "sse", "conf")}
             b = aln_amd.Batch(gpu_util.ctx(), ["A" * (len(p["conf"]) - 2) for p in qps], ["A" * (len(p["conf"]) - 2) for p in tps])
@@ -84,9 +80,6 @@ def test_full_size_exact_kernels_agree():
             sc, lists, status = b.optimal()
             b.close()
             return name, cells, sc, lists
-        finally:
-            for k in env:
-                del os.environ[k]
 
     def same(a, c):
         for p in range(len(a[1])):
@@ -97,12 +90,12 @@ def test_full_size_exact_kernels_agree():
 
     qps = [random_profile(73000, 2000), random_profile(73001, 1990)]
     tps = [random_profile(74000, 2000), random_profile(74001, 2000)]
-    tiled = run(qps, tps, [])
-    slots = run(qps, tps, ["ALN_EXACT_NO_TILES"])
+    tiled = run(qps, tps, {})
+    slots = run(qps, tps, {"exact_tiles": 0})
     assert "dp_exact_tiled" in tiled[0] and "dp_exact_blocked" in slots[0]
     same(tiled, slots)
     qps, tps = [random_profile(73002, 300)], [random_profile(74002, 700)]
-    tiled = run(qps, tps, [])
-    literal = run(qps, tps, ["ALN_EXACT_LITERAL"])
+    tiled = run(qps, tps, {})
+    literal = run(qps, tps, {"exact_literal": 1})
     assert "dp_exact_tiled" in tiled[0] and literal[0].startswith("dp_exact_kernel")
     same(tiled, literal)

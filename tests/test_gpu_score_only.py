@@ -49,12 +49,8 @@ def test_scores_equal_plane_path_and_oracle(tmax, blosum62):
     blk = aln_amd.score_all_vs_all(ctx, qs, ts, alpha, table, 11, 1, 2, 7)
     assert np.array_equal(blk, got[2:7])
     # the default is the packed two-queries-per-wave kernel; the one-query 32-bit kernel must agree
-    import os
-    os.environ["ALN_SCORE_NO_PACKED"] = "1"
-    try:
+    with ctx.hints(score_packed=0):
         assert np.array_equal(aln_amd.score_all_vs_all(ctx, qs, ts, alpha, table, 11, 1), got)
-    finally:
-        del os.environ["ALN_SCORE_NO_PACKED"]
 
 
 def test_score_only_rejects_what_it_cannot_do(blosum62):
@@ -66,3 +62,26 @@ def test_score_only_rejects_what_it_cannot_do(blosum62):
     with pytest.raises(aln_amd.AlnError) as ei:
         aln_amd.score_all_vs_all(ctx, ["ACJ"], ["ACD"], alpha, table, 11, 1)
     assert ei.value.code == aln_amd.E_RESIDUE
+
+
+def test_more_than_one_slab_of_query_rows(blosum62):
+    """> 32768 query rows: the packed kernel walks the rows in slabs of 32768 (blockIdx.y limit), each with its own length
+    order on the device; both kernels must agree on every row and equal the oracle on samples from both slabs."""
+    alpha, table = blosum62
+    ctx = gpu_util.ctx()
+    n = 32768 + 700
+    g = MT19937(99)
+    lens = (g.draw(n) % 23).astype(int)                    # 0 .. 22 residues, ragged, empties included
+    blob = residues(g, int(lens.sum()))
+    off = np.concatenate([[0], np.cumsum(lens)])
+    qs = [blob[off[k]:off[k + 1]] for k in range(n)]
+    ts = [residues(g, 30), residues(g, 7), "", residues(g, 300)]
+    got = aln_amd.score_all_vs_all(ctx, qs, ts, alpha, table, 11, 1)
+    with ctx.hints(score_packed=0):
+        plain = aln_amd.score_all_vs_all(ctx, qs, ts, alpha, table, 11, 1)
+    assert np.array_equal(got.view(np.uint32), plain.view(np.uint32))
+    for i in (0, 1, 32767, 32768, 32769, n - 1, 20000, 33000):
+        for j in range(len(ts)):
+            S = orc.sim_submatrix(qs[i], ts[j], alpha, table)
+            rc, D, PQ, PT = orc.dp_build(S, orc.Gap(orc.LOCAL, 11, 1))
+            assert got[i, j] == orc.optimal(D, PQ, PT, True)[1], (i, j)

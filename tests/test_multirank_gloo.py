@@ -1,6 +1,8 @@
-"""CPU, world_size 2, gloo: the N>1 path of bench.py — block sharding of the pair list over ranks and the single
-all_gather of the scores.  The kernels cannot run here; each rank scores its shard with the oracle (test
-infrastructure) so that the gathered vector can be checked against a single-process run."""
+"""CPU, world_size 2, gloo: the N>1 path of bench.py — the length-sorted deal of the pair list over ranks (the C ABI's
+aln_deal_units, pure host code) and the single gather of the scores.  The kernels and RCCL cannot run here;
+each rank scores its share with the oracle (test infrastructure) and gathers with aln_amd.shard.GlooComm, which has the
+interface of the RCCL-backed aln_amd.shard.Comm (tests/test_gpu_comm.py covers that one on the GPU box), so that the
+gathered vector can be checked against a single-process run."""
 import os
 import socket
 import sys
@@ -24,20 +26,24 @@ def _worker(rank, world, port, n_total, q):
         sys.path.insert(0, p)
     import torch.distributed as dist
     import orc
-    from aln_amd.shard import gather_scores, owned_range
+    from aln_amd.shard import GlooComm, deal_units, local_units
     from aln_amd.synth import random_pair
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     alpha, table = orc.load_blosum(os.path.join(ROOT, "tests", "golden", "BLOSUM62"))
-    lo, hi = owned_range(n_total, world, rank)
+    work = [(20 + p + 2) * (25 + 2) for p in range(n_total)]          # Q*T of pair p
+    owner, slot = deal_units(work, world)
+    mine = local_units(owner, slot, rank)
     local = []
-    for p in range(lo, hi):
+    for p in mine:
+        p = int(p)
         a, b = random_pair(1000 + p, 20 + p, 25)
         S = orc.sim_submatrix(a, b, alpha, table)
         rc, D, PQ, PT = orc.dp_build(S, orc.Gap(orc.LOCAL, 11, 1))
         local.append(orc.optimal(D, PQ, PT, True)[1])
-    allv = gather_scores(np.array(local, np.float32), n_total, world, rank)
+    n_max = int(np.bincount(owner, minlength=world).max())
+    allv = GlooComm(world, rank).gather(np.array(local, np.float32), mine, n_max, n_total)
     dist.barrier()
     if rank == 0:
         q.put(allv.tolist())
@@ -55,6 +61,37 @@ def test_owned_ranges_partition_the_pair_list():
             assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
 
 
+def test_sorted_deal_is_a_balanced_permutation():
+    """aln_deal_units: every unit gets exactly one (owner, slot), local lists are sorted by work descending, and the
+    per-rank sums of work differ by no more than the largest unit (boustrophedon deal of a sorted list)."""
+    sys.path.insert(0, os.path.join(ROOT, "alignment-algos_amd"))
+    from aln_amd.shard import deal_units, local_units
+    rng = np.random.RandomState(5)
+    for n in (0, 1, 7, 64, 1000, 4096):
+        for w in (1, 2, 3, 8):
+            work = (rng.randint(402, 603, size=n).astype(np.int64) * rng.randint(402, 603, size=n)) if n else np.zeros(0, np.int64)
+            owner, slot = deal_units(work, w)
+            assert ((owner >= 0) & (owner < w)).all()
+            seen = np.zeros(n, dtype=bool)
+            sums = []
+            for r in range(w):
+                mine = local_units(owner, slot, r)
+                assert sorted(slot[mine].tolist()) == list(range(len(mine)))
+                assert not seen[mine].any()
+                seen[mine] = True
+                wl = work[mine]
+                assert (np.diff(wl) <= 0).all()                         # long units first
+                sums.append(int(wl.sum()))
+            assert seen.all()
+            cnt = np.bincount(owner, minlength=w) if n else np.zeros(w, int)
+            assert cnt.max() - cnt.min() <= 1
+            if n >= w:
+                assert max(sums) - min(sums) <= int(work.max())
+    # equal work: ties keep the lower index first
+    owner, slot = deal_units([5, 5, 5, 5, 5], 2)
+    assert owner.tolist() == [0, 1, 1, 0, 0] and slot.tolist() == [0, 0, 1, 1, 2]
+
+
 def test_two_rank_gather_equals_single_process():
     import torch.multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -68,7 +105,7 @@ def test_two_rank_gather_equals_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = q.get(timeout=180)
+    got = q.get(timeout=60)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
