@@ -23,6 +23,7 @@ const HintDef kDefs[] = {
     {"h16", "ALN_NO_H16", true, &aln_hints::h16},
     {"key16", "ALN_NO_KEY16", true, &aln_hints::key16},
     {"tag_alt_prio", "ALN_TAG_ALT_PRIO", false, &aln_hints::tag_alt_prio},
+    {"tag_lag", "ALN_TAG_LAG", false, &aln_hints::tag_lag},
     {"tag_persistent", "ALN_TAG_PERSISTENT", false, &aln_hints::tag_persistent},
     {"dp_variant_nw", nullptr, false, &aln_hints::dp_nw},
     {"dp_variant_r", nullptr, false, &aln_hints::dp_r},

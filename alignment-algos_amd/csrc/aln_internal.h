@@ -60,6 +60,7 @@ struct aln_hints {
   int key16 = 1;             // 0: never use the 16-bit key layout
   int tag_alt_prio = 1;      // tagged kernel: alternate s_setprio per row by hardware-slot parity (pays on lone launches; a caller that
                              // overlaps launches of several contexts sets 0)
+  int tag_lag = 4;           // tagged kernel: rows wave w runs behind wave w-1 (skewed exchange, one barrier every tag_lag rows); 0 = synchronous
   int tag_persistent = 1;    // tagged kernel: persistent workgroups that pull pairs from a queue (0: one workgroup per pair)
   int dp_nw = 0, dp_r = 0, dp_x = 0;   // force a row-sweep variant (waves per pair, groups per lane, columns per lane and group); 0 = auto
   int exact_tiles = 1;       // 0: dp_exact_blocked instead of dp_exact_tiled where both apply

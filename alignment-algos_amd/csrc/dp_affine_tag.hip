@@ -43,6 +43,9 @@ struct TagParams {
   int gi, ge;
   int free_del, free_ins;
   int alt_prio;
+  int lag;        // 0: the waves of a pair exchange their row state synchronously (write, barrier, read inside every row);
+                  // L = 2^k >= 1: wave w runs L*w rows behind wave 0 and reads what the earlier waves left in a ring of
+                  // exchange slots, one workgroup barrier every L rows (see "skewed exchange" below)
 };
 
 template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
@@ -81,8 +84,12 @@ __device__ __forceinline__ void wave_incl_max_keys(int (&v)[R]) {
 // KBT = 13: value in bits 13..31 (|value| < 2^18).  KBT = 16 (local builds with 16-bit planes whose values provably fit 15
 // bits): the score is the key's high half and the pointer word its low half, so two cells pack into one plane word with a
 // single v_perm_b32 each and the pointer never has to be extracted.
+// 16 cells per lane need ~170 VGPRs, which would let the dispatcher place up to 3 waves on a SIMD.  A batch of 1024 pairs x 2 waves
+// is exactly 2 waves per SIMD, but the dispatcher does not spread them evenly on its own (3 on some SIMDs, 1 on others: measured
+// +20 % kernel time, and it varies with unrelated code changes).  amdgpu_waves_per_eu(2,2) makes the compiler allocate for
+// exactly two waves per SIMD (it rounds the VGPR allocation up so that a third cannot be placed), which caps every SIMD at 2.
 template <int NW, int R, bool LOCAL, bool H16, int KBT, int X>
-__global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X == 16 ? 2 : 1, R * X == 16 ? 2 : 8))) void dp_affine_tag_kernel(
     const PairDesc* __restrict__ pairs, const uint8_t* __restrict__ qcodes, const uint8_t* __restrict__ tcodes,
     const int32_t* __restrict__ table32, float* __restrict__ Hbase, uint32_t* __restrict__ Pbase,
     PairResult* __restrict__ res, TagParams prm) {
@@ -95,13 +102,10 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
   constexpr int GW = 64 * X;            // columns of one group (one lane-contiguous stretch of a row)
   __shared__ int tab[32 * 32];          // substitution scores << KB
   __shared__ uint8_t qcs[2048];         // the query's residue codes (Q <= 2048): one LDS byte per row instead of a global load
-  __shared__ __attribute__((aligned(16))) int xch[2][NW][4];
+  constexpr int RING = 16;              // exchange slots: one per row, reused every 16 rows
+  __shared__ __attribute__((aligned(16))) int xch[RING][NW][4];
   __shared__ int red[NW][2];
 
-  // 16 cells per lane need ~170 VGPRs, which would let the dispatcher place up to 3 waves on a SIMD.  A batch of 1024 pairs x 2 waves
-  // is exactly 2 waves per SIMD, but the dispatcher does not spread them evenly on its own (3 on some SIMDs, 1 on others:
-  // measured +20 % kernel time, and it varies with unrelated code changes).  Allocating >= 184 VGPRs caps every SIMD at 2.
-  if constexpr (R * X == 16) asm volatile("" ::: "v183");
   const PairDesc pd = pairs[blockIdx.x];
   const int Q = pd.Q, T = pd.T, ld = pd.ld;
   const int lane = threadIdx.x & 63;
@@ -154,7 +158,14 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
     for (int x = 0; x < X; ++x) { dk[r][x] = 0; gmx[r][x] = NEGK; pf[r][x] = kNullPtr; }
   }
   int lmax = 0; uint32_t lpos = 0;
-  int par = 0;
+  // Skewed exchange.  Only later waves depend on earlier ones (deletion scans run left to right, the boundary cell of wave v is
+  // the first column of wave v+1; nothing flows back), so wave w may run behind wave v < w by any number of rows.  With
+  // lag = L > 0 wave w handles row (it - L*w) in iteration `it`: what wave v wrote for that row (iteration row + L*v) is at least L
+  // iterations old, and one barrier every L iterations separates every write from its reads and every read from the slot's reuse
+  // (slot = row mod 16; L * (NW-1) + L <= 16).  The LDS write -> wait -> barrier -> read -> wait chain that sat inside every row
+  // is gone: the reads are issued at the top of an iteration from a slot that has long been written.  lag = 0 keeps the
+  // synchronous form (write, barrier, read in every row); row 1 always uses it.
+  const int lag = (NW > 1) ? prm.lag : 0;
 
   // 16-bit planes are stored through buffer descriptors that cover ONE ROW (base = the row, num_records = 2*ld bytes),
   // rebuilt per row with scalar instructions: lanes of a partial last group (columns >= ld) are dropped by the memory
@@ -200,7 +211,7 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
 
   // Finish the row held in dk[]/pf[] (complete except, for w > 0, the wave's first column which the previous wave
   // computed and passes as (dB,pB)): prefix-scan preparation for the next row, exchange, local-max tracking, store.
-  auto finish_row = [&](int i, int dB, uint32_t pB) {
+  auto finish_row = [&](int i, int dB, uint32_t pB, bool sync, const int4 (&xin)[NW > 1 ? NW - 1 : 1]) {
     int sk = NEGK;     // scalar carry: prefix key over this wave's earlier groups
     int ik[R];
 #pragma unroll
@@ -221,16 +232,17 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
       sk = max(sk, __builtin_amdgcn_readlane(ik[r], 63));
     }
     if (NW > 1) {
-      if (lane == 63) { xch[par][w][0] = sk; xch[par][w][1] = dB; xch[par][w][2] = (int)pB; }
+      const int slot = i & (RING - 1);
+      if (lane == 63) { xch[slot][w][0] = sk; xch[slot][w][1] = dB; xch[slot][w][2] = (int)pB; }
       // LDS-only barrier: a __syncthreads() would also wait (vmcnt(0)) for this row's global stores to be acknowledged
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (sync) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (w > 0) {
         int fk = NEGK;                                      // prefix over columns 1 .. W0-1
         int d0 = 0; uint32_t p0 = kNullPtr;
 #pragma unroll
         for (int v = 0; v < NW - 1; ++v) {
           if (v < w) {                                      // wave-uniform; one ds_read_b128 per earlier wave
-            const int4 t = *reinterpret_cast<const int4*>(&xch[par][v][0]);
+            const int4 t = sync ? *reinterpret_cast<const int4*>(&xch[slot][v][0]) : xin[v];
             fk = max(fk, t.x);
             if (v < w - 1) {
               const int Cn = (v + 1) * GW * R;
@@ -249,7 +261,6 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
           cvk[r] = nv;
         }
       }
-      par ^= 1;
     }
     if (LOCAL) {
       int rm = 0;
@@ -289,7 +300,8 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
       for (int x = 0; x < X; ++x) row1(cb + GW * r + x, tab_at(qrow, code4[r][x]), dk[r][x], pf[r][x]);
     int dB = 0; uint32_t pB = kNullPtr;
     if (NW > 1) row1(CB, tab_at(qrow, codeB4), dB, pB);
-    finish_row(1, dB, pB);
+    const int4 none[NW > 1 ? NW - 1 : 1] = {};
+    finish_row(1, dB, pB, true, none);
   }
 
   // ---- interior rows 2 .. Q-2 (dpmatrix.h:447-486 / :607-649) ---------------------------------------------
@@ -301,7 +313,16 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
   const int hwslot = (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_ID.WAVE_ID: this wave's slot on its SIMD
   int code_n1 = (Q >= 5) ? (int)qcs[3] : 0;                                     // residue of row i+1
   int rowv_next = tab_at(((Q >= 4) ? (int)qcs[2] : 0) * 128, lane_row4);        // table row of row i
-  for (int i = 2; i <= Q - 2; ++i) {
+  const int it_end = Q - 2 + lag * (NW - 1);
+  for (int it = 2; it <= it_end; ++it) {
+    const int i = it - lag * w;                                                  // the row this wave handles now
+    const bool sync = lag == 0;
+    if (i >= 2 && i <= Q - 2) {
+    int4 xin[NW > 1 ? NW - 1 : 1];
+    if (NW > 1 && !sync && w > 0) {
+#pragma unroll
+      for (int v = 0; v < NW - 1; ++v) if (v < w) xin[v] = *reinterpret_cast<const int4*>(&xch[i & (RING - 1)][v][0]);
+    }
     // The SIMD's arbiter favours its older wave: of the 4 pairs of a CU the first finishes after 2.4 ms, the last after
     // 3.3 ms, and the SIMD idles behind the early finishers.  Alternating the user priority row by row (by the parity of
     // the wave's hardware slot) evens that out: -3...-6 % on a lone launch.  Launches that overlap on several streams
@@ -388,7 +409,9 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_tag_kernel(
         }
       }
     }
-    finish_row(i, dB, pB);
+    finish_row(i, dB, pB, sync, xin);
+    }
+    if (NW > 1 && !sync && (it & (lag - 1)) == lag - 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
 
   // ---- last row: untouched except the corner, which dp_corner_kernel writes --------------------------------
@@ -452,7 +475,9 @@ static bool tag_key16_legal(const aln_batch* b) {
 }
 
 template <int NW, int R, int X>
-static int launch_tag_variant(aln_batch* b, const TagParams& prm) {
+static int launch_tag_variant(aln_batch* b, const TagParams& prm_in) {
+  TagParams prm = prm_in;
+  while (prm.lag * NW > 16) prm.lag >>= 1;                 // the ring has 16 slots: lag * (NW-1) + lag <= 16
   dim3 grid(b->n_pairs), block(64 * NW);
   hipStream_t st = b->ctx->stream;
   const bool k16 = b->islocal && b->h_mode == 1 && tag_key16_legal(b) && b->ctx->hints.key16;
@@ -485,6 +510,8 @@ int launch_dp_affine_tag(aln_batch* b) {
   // row-alternating wave priority: a per-context hint (aln_ctx_set_hint "tag_alt_prio"): it pays while launches follow each other
   // on one stream (the arbiter's favouritism costs ~6 %) and loses when the caller overlaps launches of several contexts
   prm.alt_prio = b->ctx->hints.tag_alt_prio;
+  prm.lag = b->ctx->hints.tag_lag;
+  if (prm.lag < 0 || prm.lag > 4 || (prm.lag & (prm.lag - 1))) prm.lag = 0;      // 0, 1, 2 or 4: lag * (NW-1) + lag <= 16 slots for NW <= 4
   const int ld = row_stride(b->maxT);
   // variant = waves per pair, groups per lane, consecutive columns a lane owns in a group (ALN_DP_VARIANT="NW,R[,X]")
   int nw = b->ctx->hints.dp_nw, r = b->ctx->hints.dp_r, x = b->ctx->hints.dp_x ? b->ctx->hints.dp_x : 4;

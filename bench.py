@@ -1,15 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py — BASELINE.json config 2 on N MI355X: batched local affine-gap DP (BLOSUM62, 11/1) over 1024
-synthetic 2000 x 2000 pairs per GPU, DP build + find_max + pointer traceback, through the C ABI.
+"""bench.py — BASELINE.json config 2 on N MI355X: batched local affine-gap DP (BLOSUM62, 11/1) over 1024 synthetic
+2000 x 2000 pairs per GPU — DP build + find_max + pointer traceback — through the C ABI (libalnhip.so).
 
-A step = one pass of the hot path (aln_batch_dp + aln_batch_optimal) over the resident batch of 1024 pairs, issued as
---split launches that rotate over --streams HIP streams (see main()); sequences are uploaded to HBM before the timed region.  Pairs are independent, so ranks own disjoint batches (weak scaling)
-and the only collective is one all_gather of the fp32 scores per step (RCCL over xGMI).
+A step = one pass of the hot path over the resident batch: aln_batch_reevaluate (DP + corner kernels) +
+aln_batch_optimal_enqueue/_collect (find_max + traceback, per-pair results to the host).  Sequences are resident in HBM
+before the timed region.  Pairs are independent, so ranks own disjoint batches (weak scaling) and the only collective is ONE
+gather of the fp32 scores per step: aln_gather_scores (RCCL all-gather over xGMI, csrc/aln_comm.hip) — never torch.
 
-Prints ONE JSON line: metric GCUPS = sum |q|*|t| of all ranks / wall seconds (max over ranks), plus
-  roofline     — dominant kernel (row-sweep DP) algorithmic bytes (8 B/cell) / its mean HIP-event duration
-  cpu_baseline — the reference (oracle/_ref, real christang/alignment-algos DPMatrix) or the oracle port timed
-                 on this box's host cores, rank 0 at N=1, one pair of the same workload per core (bounded sample).
+Prints ONE JSON line.  Besides the contract's keys:
+  roofline      dominant kernel (row-sweep DP).  `achieved` uses the bytes the chosen plane layout MUST write (uint16 score +
+                uint16 pointer word = 4 B per matrix cell in this configuration; `contract_bytes` keeps SURVEY 8(d)'s 8 B/cell for
+                context) over the measured time; `valu` is the second roof (wave-instructions from profiles/ over the measured
+                VALU issue rate); `bound` names the roof with the larger fraction.
+  kernel_only / end_to_end   SURVEY 8(d): kernel time alone, and a pass that also encodes + uploads the residues, copies every
+                pair list to the host and builds the gapped strings + identities (aln_batch_optimal_strings).
+  secondary     driver-timed figures of configs 3, 4 and 5 on this GPU (rank 0, N = 1).
+  cpu_baseline  the reference (oracle/_ref, the real christang/alignment-algos DPMatrix) or the oracle port on this box's host
+                cores: one pair alone on an idle core, then one pair per core on all cores.
 """
 import argparse
 import json
@@ -23,7 +30,10 @@ sys.path.insert(0, os.path.join(ROOT, "alignment-algos_amd"))
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300-6900 GB/s is what a plain fill reaches
+# gfx950 VALU issue, measured with tools/valu_rate2.hip / valu_occ.hip: ns per wave64 instruction and SIMD with >= 2 waves issuing
+VALU_NS_FULL, VALU_NS_HALF = 0.92, 1.58
+N_SIMD = 1024
 
 
 def make_workload(rank, n_pairs, length):
@@ -38,10 +48,20 @@ def make_workload(rank, n_pairs, length):
     return qs, ts
 
 
+def load_blosum():
+    lines = open(os.path.join(ROOT, "tests", "golden", "BLOSUM62")).read().split("\n")
+    k = 0
+    while lines[k].startswith("#"):
+        k += 1
+    alphabet = "".join(lines[k].split())
+    table = np.array([[float(x) for x in l.split()[1:]] for l in lines[k + 1:k + 1 + len(alphabet)]], dtype=np.float32)
+    return alphabet, table
+
+
 def cpu_baseline(qs, ts, mode, gi, ge):
-    """the reference's DPMatrix constructor on this box's host cores — one pair per core on all cores the
-    process may use (bounded sample: the first C pairs of rank 0's workload, ~20-30 s), plus the one-core figure
-    (the fastest single pair of that run).  The real reference binary (oracle/_ref) if it travelled, else the oracle."""
+    """SURVEY 8(d): the reference's DPMatrix constructor on this box's host cores.  (1) ONE pair on an otherwise idle core;
+    (2) one pair per core on all cores the process may use (the first C pairs of rank 0's workload).  The real reference
+    binary (oracle/_ref) if it travelled, else the oracle port.  Bounded: about 25 s + 50 s."""
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     blosum = os.path.join(ROOT, "tests", "golden", "BLOSUM62")
     try:
@@ -49,21 +69,25 @@ def cpu_baseline(qs, ts, mode, gi, ge):
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, len(qs), 16))      # the GPU box gives one GPU a 16-core share
-    cells = sum(len(qs[p]) * len(ts[p]) for p in range(cores))
-    sample = "%d pairs %dx%d of the bench workload (rank 0, pairs 0..%d), one pair per core, DPMatrix build only" % (
-        cores, len(qs[0]), len(ts[0]), cores - 1)
-    t0 = time.time()
     if os.path.exists(harness):
-        procs = [subprocess.Popen([harness, "aa", blosum, str(mode), str(gi), str(ge), "fwd", qs[p], ts[p], "ctime", "corner"],
-                                  stdout=subprocess.PIPE, text=True) for p in range(cores)]
-        per = []
-        for pr in procs:
+        kind = "reference"
+
+        def start(p):
+            return subprocess.Popen([harness, "aa", blosum, str(mode), str(gi), str(ge), "fwd", qs[p], ts[p], "ctime", "corner"],
+                                    stdout=subprocess.PIPE, text=True)
+
+        def finish(pr):
             out = pr.communicate()[0]
             if pr.returncode != 0:
                 raise RuntimeError("reference harness failed")
-            per.append([float(l.split()[1]) for l in out.split("\n") if l.startswith("CTIME")][0])
-        kind = "reference"
+            return [float(l.split()[1]) for l in out.split("\n") if l.startswith("CTIME")][0]
+        t0 = time.time()
+        alone = finish(start(0))
+        t1 = time.time()
+        per = [finish(pr) for pr in [start(p) for p in range(cores)]]
+        wall = time.time() - t1
     else:
+        kind = "port"
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import orc
         from concurrent.futures import ThreadPoolExecutor
@@ -74,12 +98,95 @@ def cpu_baseline(qs, ts, mode, gi, ge):
             t1 = time.time()
             orc.dp_build(S, orc.Gap(mode, gi, ge))
             return time.time() - t1
+        alone = one(0)
+        t1 = time.time()
         with ThreadPoolExecutor(cores) as ex:
             per = list(ex.map(one, range(cores)))
-        kind = "port"
-    wall = time.time() - t0
-    return {"value": cells / wall / 1e9, "unit": "GCUPS", "cores": cores, "kind": kind, "sample": sample, "seconds": round(wall, 3),
-            "single_core_value": len(qs[0]) * len(ts[0]) / min(per) / 1e9, "single_core_seconds": round(min(per), 3)}
+        wall = time.time() - t1
+    cells = sum(len(qs[p]) * len(ts[p]) for p in range(cores))
+    return {"value": cells / wall / 1e9, "unit": "GCUPS", "cores": cores, "kind": kind,
+            "sample": "%d pairs %dx%d of the bench workload (rank 0, pairs 0..%d), one pair per core, DPMatrix build only; "
+                      "single_core_value = pair 0 run alone first" % (cores, len(qs[0]), len(ts[0]), cores - 1),
+            "seconds": round(wall, 3), "slowest_pair_seconds": round(max(per), 3),
+            "single_core_value": len(qs[0]) * len(ts[0]) / alone / 1e9, "single_core_seconds": round(alone, 3)}
+
+
+def pinned_scores(rank, n_pairs, length):
+    """Optimal scores of the bench pairs the REAL reference was run on (tests/golden/full_cases.json, oracle/gen_golden_full.py)."""
+    path = os.path.join(ROOT, "tests", "golden", "full_cases.json")
+    if rank != 0 or length != 2000 or not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        doc = json.load(f)
+    return {g["pair"]: np.array([g["opt"]["score"]], dtype=np.uint32).view(np.float32)[0] for g in doc["c2"]["pairs"] if g["pair"] < n_pairs}
+
+
+def secondary_configs(aln_amd, ctx, alphabet, table, qs, ts, length):
+    """Configs 3, 4, 5 on this GPU, timed here (wall clock around synchronised calls) so that they are the driver's numbers
+    too.  Every figure names its workload; the parity tests of the same entry points are tests/test_gpu_full_size.py."""
+    from aln_amd.synth import MT19937, make_subopt_regions, random_profile, residues
+    out = {}
+    n = len(qs)
+    # ---- config 4: top-K=256 near-optimal alignments per pair from the resident config-2 matrices
+    b = aln_amd.Batch(ctx, qs, ts)
+    b.dp_submatrix(alphabet, table, aln_amd.LOCAL, 11, 1, aln_amd.FWD, aln_amd.DP_FAST)
+    ctx.synchronize()
+    flags = make_subopt_regions(length + 2, 10)
+    best = None
+    for rep in range(2):
+        t0 = time.perf_counter()
+        n_out, scores, lengths, _, status = b.enumerate_all("cw", 256, 0.01, flags, K=258, node_cap=1 << 24, ali_cap=1 << 15,
+                                                            want_pairs=False, raise_on_overflow=False)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    sm, um = b.last_enum_ms()
+    out["c4"] = {"workload": "config 4: %d pairs %dx%d resident from the config-2 build, ConstrainedNearOptimal NUM_SUBOPT=256, "
+                             "DELTA_RATIO 0.01 (the largest of {0.05, 0.01, 0.005} the reference finishes on these homologs), "
+                             "make_subopt_regions(T,10)" % (n, length, length),
+                 "value": round(float(n_out.sum()) / best, 1), "unit": "alignments/s", "seconds": round(best, 4),
+                 "alignments": int(n_out.sum()), "aligned_pairs_emitted": int(lengths[lengths > 0].sum()),
+                 "search_kernel_ms": round(sm, 3), "unroll_kernel_ms": round(um, 3), "pairs_overflowed": int((status != 0).sum())}
+    b.close()
+    # ---- config 3: Hmap2Eval profile-profile, global, exact-order DP
+    n_prof = 64
+    qps = [random_profile(3000 + p, length) for p in range(n_prof)]
+    tps = [random_profile(4000 + p, length) for p in range(n_prof)]
+    qpool = {k: np.concatenate([p[k] for p in qps]) for k in ("aa", "sse", "conf")}
+    tpool = {k: np.concatenate([p[k] for p in tps]) for k in ("aa", "sse", "conf")}
+    q_idx = np.arange(n) % n_prof
+    t_idx = (np.arange(n) * 7 + np.arange(n) // n_prof) % n_prof
+    b = aln_amd.Batch(ctx, ["A" * length] * n_prof, ["A" * length] * n_prof, q_idx, t_idx)
+    best = None
+    for rep in range(2):
+        t0 = time.perf_counter()
+        b.dp_hmap2(qpool, tpool, aln_amd.GLOBAL, 4.73, 0.34, 0.5, 1.0, 0.12)
+        sc, _, st = b.optimal(want_pairs=False)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    inner = n * float(length + 2) ** 2 * (2 * length + 4) / 2.0
+    out["c3"] = {"workload": "config 3: %d pairs %dx%d (%d + %d distinct synthetic HMAP profiles), Hmap2Eval similarity + z-normalisation "
+                             "on the device, min(t1,t2) position gaps 4.73/0.34, global, exact-order DP + Optimal; profile upload included"
+                             % (n, length, length, n_prof, n_prof),
+                 "value": round(n * length * length / best / 1e9, 3), "unit": "GCUPS", "seconds": round(best, 4),
+                 "dp_kernel_ms": round(b.last_dp_ms(), 2), "inner_k_evals_per_s": round(inner / (b.last_dp_ms() * 1e-3), 1),
+                 "kernel": b.kernel_name(), "bound": "valu"}
+    b.close()
+    # ---- config 5: one rank's block of the 4096 x 4096 all-vs-all (512 query rows x 4096 templates), scores only
+    seqs = []
+    for s in range(4096):
+        g = MT19937(5000 + s)
+        ln = 400 + int(g.draw(1)[0] % 201)
+        seqs.append(residues(g, ln))
+    pool = aln_amd.SeqPool(seqs)
+    aln_amd.score_all_vs_all(ctx, pool, pool, alphabet, table, 11, 1, 0, 32)
+    t0 = time.perf_counter()
+    aln_amd.score_all_vs_all(ctx, pool, pool, alphabet, table, 11, 1, 0, 512)
+    dt = time.perf_counter() - t0
+    cells = float(sum(len(s) for s in seqs[:512])) * float(sum(len(s) for s in seqs))
+    out["c5"] = {"workload": "config 5, one of 8 ranks' share: 512 query rows x 4096 templates of the 4096-sequence set (400-600 aa), "
+                             "local 11/1, scores only; residue upload and score download included",
+                 "value": round(cells / dt / 1e9, 1), "unit": "GCUPS", "seconds": round(dt, 4), "bound": "valu"}
+    return out
 
 
 def main():
@@ -90,6 +197,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=1024, help="pairs per GPU (config 2: 1024)")
     ap.add_argument("--length", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config 3/4/5 figures and the end-to-end pass")
     ap.add_argument("--streams", "--batches", dest="batches", type=int, default=4,
                     help="HIP streams (contexts) the launches rotate over (1 = everything on one stream)")
     ap.add_argument("--split", type=int, default=2,
@@ -117,30 +225,23 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import aln_amd
-    blosum = os.path.join(ROOT, "tests", "golden", "BLOSUM62")
-    lines = open(blosum).read().split("\n")
-    k = 0
-    while lines[k].startswith("#"):
-        k += 1
-    alphabet = "".join(lines[k].split())
-    table = np.array([[float(x) for x in l.split()[1:]] for l in lines[k + 1:k + 1 + len(alphabet)]], dtype=np.float32)
-
+    from aln_amd.shard import Comm, GlooComm
+    alphabet, table = load_blosum()
     mode, gi, ge = aln_amd.LOCAL, 11, 1
     qs, ts = make_workload(rank, args.pairs, args.length)
     # How a step's batch reaches the GPU.  The batch of `pairs` pairs is processed as `split` sub-batches (pairs/split pairs
     # each, one launch sequence each) and consecutive launches rotate over `streams` contexts, each with its own HIP stream:
     # launch j runs sub-batch j % split on stream j % streams.  Launches of different streams overlap, so there are always
-    # undispatched pairs to take the SIMD slots that finished pairs free (a lone 1024-pair launch fills the GPU exactly
-    # once and leaves early-finishing SIMDs idle: DESIGN.md 4.1), and the O(Q+T) corner kernel and the traceback run
-    # beside the next DP kernel.  Measured on one box, ms per 1024 pairs: 1 stream x 1024 pairs 3.3-3.6; 2 streams x 1024
-    # pairs 2.8-3.8 depending on the phase the two streams fall into; 3 streams x 512 pairs 2.70-2.97; 4 streams x 512
-    # pairs 2.69-2.76 (the default); 5 x 512: 3.57; 3 x 256: 3.76.  Every step still builds, scans and traces all `pairs`
-    # pairs; every (stream, sub-batch) combination that occurs has its own resident planes.
+    # undispatched pairs to take the SIMD slots that finished pairs free, and the O(Q+T) corner kernel and the traceback run
+    # beside the next DP kernel.  Every step still builds, scans and traces all `pairs` pairs; every (stream, sub-batch)
+    # combination that occurs has its own resident planes.  --streams 1 --split 1 = one lone launch per step.
     nb = max(1, args.batches)
     split = args.split if (args.split >= 1 and args.pairs % max(1, args.split) == 0) else 1
     ph = args.pairs // split
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nb - 1)]
     ctxs = [aln_amd.Context(local_rank, st.cuda_stream) for st in streams]
+    for c in ctxs:
+        c.set_hint("tag_alt_prio", 1 if nb == 1 else 0)    # the row-alternating priority pays on lone launches only
     units = {}                                              # (stream, sub-batch) -> resident batch object
     j = 0
     while (j % nb, j % split) not in units:
@@ -154,37 +255,45 @@ def main():
         bt.dp_submatrix(alphabet, table, mode, gi, ge, aln_amd.FWD, aln_amd.DP_FAST)
     batch = batches[0]
 
-    from aln_amd.shard import gather_scores
+    # the one collective of the path: every rank's scores, gathered by the C ABI (RCCL); its own context/stream, so that waiting
+    # for the gathered scores does not wait for compute kernels queued on the launch streams
+    comm = comm_ctx = None
+    if world > 1:
+        if rehearse:
+            comm = GlooComm(world, rank)
+        else:
+            comm_ctx = aln_amd.Context(local_rank)
+            comm = Comm(comm_ctx, world, rank)
+    n_total = args.pairs * world
+    gathered = np.zeros(n_total, dtype=np.float32)
+    sub_index = [np.arange(rank * args.pairs + h * ph, rank * args.pairs + (h + 1) * ph, dtype=np.int32) for h in range(split)]
 
-    # A step = DPMatrix::reevaluate (DP + corner kernels) + Optimal (find_max + traceback kernels, per-pair results copied to the
-    # host) [+ the gather of the scores over the ranks].  Steps are software-pipelined: step k's kernels and result copy are
-    # enqueued, then step k-1's results are collected (and gathered), so the host's launch / copy latency hides behind the
-    # kernels of the next step.  Every enqueued step is collected inside the timed region.
-    queue = []                                              # batches with an enqueued, not yet collected step (oldest first)
+    queue = []                                              # (batch, sub-batch) with an enqueued, not yet collected step (oldest first)
     count = [0]
-    side = torch.cuda.Stream(dev) if (world > 1 and not rehearse) else None    # the score gather does not queue behind the kernels
 
     def collect():
-        sc, cnt, status = queue.pop(0).optimal_collect()
-        if world > 1:                                       # the one collective of the path: all ranks' scores (RCCL)
-            gather_scores(sc, len(sc) * world, world, rank, device=None if rehearse else dev, stream=side)
+        bt, h = queue.pop(0)
+        sc, cnt, status = bt.optimal_collect()
+        if comm is not None:
+            comm.gather(sc, sub_index[h], ph, n_total, out=gathered)
+        else:
+            gathered[sub_index[h]] = sc
         return sc, status
 
     def launch():                                           # one sub-batch: build + find_max + traceback, results to the host
-        bt = units[(count[0] % nb, count[0] % split)]
+        k = (count[0] % nb, count[0] % split)
+        bt = units[k]
         count[0] += 1
-        while bt in queue:                                  # its previous results must be read out before its planes are rebuilt
+        while any(q[0] is bt for q in queue):               # its previous results must be read out before its planes are rebuilt
             collect()
         bt.reevaluate()
         bt.optimal_enqueue()
-        queue.append(bt)
+        queue.append((bt, k[1]))
         return collect() if len(queue) > nb else (None, None)
 
     def step():                                             # all sub-batches of the batch
-        out = (None, None)
         for _ in range(split):
-            out = launch()
-        return out
+            launch()
 
     def drain():
         out = (None, None)
@@ -216,15 +325,22 @@ def main():
         per[k] = per.get(k, 0) + 1
     kernel_ms = np.concatenate([units[k].dp_ms_history(min(n, 64)) for k, n in per.items()])
     assert (status == 0).all()
-    ref_sc = {}                                             # same inputs -> identical results, whichever stream ran them
+    # parity inside the bench: every resident copy of a sub-batch gives identical scores, and the pairs the REAL reference
+    # was run on (tests/golden/full_cases.json) score exactly what it scored
+    ref_sc = {}
     for (sidx, h), bt in units.items():
         bt.reevaluate()
-        s_b, _, st_b = bt.optimal()
+        s_b, _, st_b = bt.optimal(want_pairs=False)
         assert (st_b == 0).all()
         if h not in ref_sc:
             ref_sc[h] = np.array(s_b, copy=True)
         else:
             assert np.array_equal(ref_sc[h], s_b), "resident copies of a sub-batch disagree"
+    all_sc = np.concatenate([ref_sc[h] for h in range(split)])
+    assert np.array_equal(gathered[rank * args.pairs:(rank + 1) * args.pairs].view(np.uint32), all_sc.view(np.uint32)), "gathered scores differ"
+    pins = pinned_scores(rank, args.pairs, args.length)
+    for p, want in pins.items():
+        assert np.float32(all_sc[p]).view(np.uint32) == np.float32(want).view(np.uint32), "pair %d: score %r, reference %r" % (p, all_sc[p], want)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -252,49 +368,97 @@ def main():
         first_of.setdefault(h, bt)
     cells_per_step = sum(first_of[h].cells() for h in range(split)) * world
     value = cells_per_step * args.steps / elapsed / 1e9
+    ms_per_step = elapsed / args.steps * 1e3
     dp_ms = float(np.mean(kernel_ms))
-    algo_bytes = batch.algorithmic_bytes()                  # of one launch (one sub-batch)
+    algo_bytes = batch.algorithmic_bytes()                  # of one launch (one sub-batch), with the layout the kernel chose
+    contract_bytes = batch.contract_bytes()
     if nb == 1:
         achieved = algo_bytes / (dp_ms * 1e-3) / 1e9
-        how = "algorithmic bytes per launch / average launch duration (HIP events on the launch stream)"
+        how = "bytes the chosen layout must write per launch / average launch duration (HIP events on the launch stream)"
     else:
         # Launches of different resident batches overlap on the GPU, so a launch's own duration (kernel_ms, what rocprofv3
-        # also reports) is not the time the device spends per launch.  The aggregate rate of the kernel is bounded from
-        # below by all timed launches' algorithmic bytes over the wall time of the timed region, which also contains the
-        # corner and traceback kernels; that lower bound is what is reported.
+        # also reports) is not the time the device spends per launch.  The kernel's aggregate rate is bounded from below by
+        # all timed launches' bytes over the wall time of the timed region (which also holds the corner and traceback kernels).
         achieved = algo_bytes * args.steps * split / elapsed / 1e9
-        how = ("launches of %d streams overlap: algorithmic bytes of all timed launches / wall time of the timed region (lower "
-               "bound; kernel_ms is one launch's own duration while it shares the GPU)" % nb)
-    traffic = None
+        how = ("launches of %d streams overlap: bytes the chosen layout must write, all timed launches / wall time of the timed "
+               "region (lower bound; kernel_ms is one launch's own duration while it shares the GPU)" % nb)
+    traffic = valu = None
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tfile) and args.length == 2000:       # only if the PMC pass was taken on exactly this launch shape
         try:
             tj = json.load(open(tfile))
-            if tj.get("launch_pairs", 1024) == ph:
+            if tj.get("launch_pairs", 1024) == ph and tj.get("kernel", batch.kernel_name()) == batch.kernel_name():
                 traffic = tj.get("hbm_bytes_per_launch")
+                if tj.get("valu_insts_per_launch"):
+                    ins = float(tj["valu_insts_per_launch"]) * split          # wave-instructions per step
+                    half = float(tj.get("valu_half_rate_share", 0.57))
+                    ns = (1 - half) * VALU_NS_FULL + half * VALU_NS_HALF
+                    floor_ms = ins / N_SIMD * ns * 1e-6
+                    valu = {"insts_per_step": ins, "source": tj.get("source"), "half_rate_share": half,
+                            "issue_ns_per_inst_per_simd": {"full_rate": VALU_NS_FULL, "half_rate": VALU_NS_HALF, "this_mix": round(ns, 3)},
+                            "issue_floor_ms_per_step": round(floor_ms, 3), "frac": round(floor_ms / (ms_per_step / 1.0), 4)}
         except Exception:
-            traffic = None
+            traffic = valu = None
+    hbm_frac = achieved / HBM_PEAK_GBS
     out = {
         "metric": "GCUPS (DP cell updates/s) at 1/2/4/8 MI355X; bit-exact score vs ref",
         "value": round(value, 3), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": "config 2: %d synthetic %dx%d pairs per GPU, local SW, affine gap 11/1, BLOSUM62 submatrix evaluator, "
                                "DP build + find_max + traceback" % (args.pairs, args.length, args.length),
-                   "pairs_per_gpu": args.pairs, "parallelism": "pair-batch sharded, %d rank(s), all_gather of scores" % world,
-                   "kernel": batch.kernel_name(), "launch_pairs": ph, "launches_per_step": split, "streams": nb},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                   "pairs_per_gpu": args.pairs, "parallelism": "pair-batch sharded, %d rank(s), one RCCL all-gather of the scores per step "
+                   "(aln_gather_scores)" % world,
+                   "kernel": batch.kernel_name(), "launch_pairs": ph, "launches_per_step": split, "streams": nb,
+                   "pairs_checked_against_reference_scores": sorted(pins)},
+        "roofline": {"bound": "hbm" if (valu is None or hbm_frac >= valu["frac"]) else "valu",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(hbm_frac, 4), "traffic": traffic,
+                     "algorithmic_bytes": algo_bytes, "bytes_per_cell": batch.plane_bytes_per_cell(),
+                     "contract_bytes": contract_bytes, "contract_note": "SURVEY 8(d) counts 8 B/cell (fp32 score + 32-bit pointer); this "
+                     "kernel stores uint16 score + uint16 pointer word, so only algorithmic_bytes are written and `achieved` uses them",
                      "kernel_ms": round(dp_ms, 3), "concurrent_launches": nb, "achieved_is": how,
-                     "algorithmic_bytes": algo_bytes,
-                     "measured_fill_GBs_this_box": round(fill_gbs, 1) if fill_gbs else None},
+                     "measured_fill_GBs_this_box": round(fill_gbs, 1) if fill_gbs else None,
+                     "frac_of_measured_fill": round(achieved / fill_gbs, 4) if fill_gbs else None,
+                     "valu": valu},
+        "kernel_only": {"ms_per_step": round(dp_ms * split, 3) if nb == 1 else None,
+                        "value": round(cells_per_step / world / (dp_ms * split * 1e-3) / 1e9, 1) if nb == 1 else None,
+                        "note": "DP kernel alone (HIP events); with overlapping streams a launch's own duration is not device time "
+                                "per launch, so it is only given for --streams 1", "launch_ms": round(dp_ms, 3)},
     }
+    for bt in batches:
+        bt.close()
+    if rank == 0 and world == 1 and not args.no_secondary:
+        # end to end: residues encoded + uploaded, DP, find_max + traceback, every pair list to the host, gapped
+        # strings + identities built — one lone launch sequence per step on one stream, nothing pipelined
+        c0 = ctxs[0]
+        c0.set_hint("tag_alt_prio", 1)
+        be = aln_amd.Batch(c0, qs, ts)
+        be.dp_submatrix(alphabet, table, mode, gi, ge, aln_amd.FWD, aln_amd.DP_FAST)
+        be.optimal_strings(decode=False)
+        n_e2e = 5
+        c0.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_e2e):
+            be.dp_submatrix(alphabet, table, mode, gi, ge, aln_amd.FWD, aln_amd.DP_FAST)     # encode + H2D + DP + corner
+            e_sc, e_id, e_st, _, _, e_len, _ = be.optimal_strings(decode=False)               # traceback + D2H + strings
+        e2e = (time.perf_counter() - t0) / n_e2e
+        assert (e_st == 0).all() and (e_len > 0).all()
+        assert np.array_equal(e_sc.view(np.uint32), all_sc.view(np.uint32))
+        out["end_to_end"] = {"ms_per_step": round(e2e * 1e3, 3), "value": round(be.cells() / e2e / 1e9, 1), "unit": "GCUPS", "steps": n_e2e,
+                             "includes": "residue encoding + H2D of codes and table, DP + corner kernels, find_max + traceback, D2H of all "
+                                         "%d pair lists, SequenceGaps strings + calcIdentity on the host (one thread); one stream, no "
+                                         "pipelining" % args.pairs}
+        be.close()
+        out["secondary"] = secondary_configs(aln_amd, c0, alphabet, table, qs, ts, args.length)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(qs, ts, mode, gi, ge)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    for bt in batches:
-        bt.close()
+    if comm is not None:
+        comm.close()
+    if comm_ctx is not None:
+        comm_ctx.close()
     for c in ctxs:
         c.close()
     if world > 1:

@@ -14,7 +14,7 @@
 // "reference" CPU baseline in bench.py (the binary travels, the sources do not).
 //
 // Usage: ref_harness <cmd> ...   (all results on stdout, floats as hex bit patterns)
-//   aa <blosum> <align_t> <gi> <ge> <fwd|rev> <query> <templ> [dump] [opt] [cw N delta flags] [ucw N delta]
+//   aa <blosum> <align_t> <gi> <ge> <fwd|rev> <query> <templ> [dump] [opt] [cw N delta flags] [ucw N delta] [cwcount delta flags]
 //   sub <blosum> <align_t> <gi> <ge> <fwd|rev> <query> <templ> q1 t1 q2 t2   (7-arg ctor + Optimal_Subali)
 //   time <blosum> <align_t> <gi> <ge> <len> <seed> <npairs>    (times the DPMatrix ctor)
 //   block <blosum> <align_t> <gi> <ge> <seqfile> r0 r1 c0 c1   (score Optimal reports for every (row, col) of a sequence set)
@@ -247,6 +247,21 @@ int main(int argc, char** argv) {
           AASet as(dpm, opt);
           dump_set("OPT", as);
         }
+      } else if (op == "cwcount") {   // cwcount delta flags: alignments ConstrainedNearOptimal creates before sortSet cuts the set
+        NOaliParams noa;
+        noa.number_suboptimal = 2000000000;
+        noa.delta_ratio = (float)atof(argv[a + 1]);
+        Optimal<AASequence, AASequence, AAEval> opt(p.align_type);
+        AASet as(dpm, opt);
+        std::string fl = argv[a + 2];
+        SuboptFlags sf(true, t.size());
+        for (size_t i = 0; i < fl.size(); ++i) sf.Set(i, fl[i] != '0');
+        ConstrainedNearOptimal<AASequence, AASequence, AAEval> c(noa, sf);
+        c.enumerate(dpm, as);
+        size_t pairs_total = 0;
+        for (size_t k = 0; k < as.size(); ++k) pairs_total += as[k].size();
+        printf("CWCOUNT %d %zu\n", (int)as.size(), pairs_total);
+        a += 2;
       } else if (op == "cw" || op == "ucw") {
         NOaliParams noa;
         noa.number_suboptimal = atoi(argv[a + 1]);

@@ -692,3 +692,38 @@ def test_optimal_strings_equal_the_reference(blosum62):
             assert goldens.f32bits(ident[k]) == ref["alis"][0]["identity"], c["name"]
             assert tl[k] == ref["tstr"] and ql[k] == ref["alis"][0]["qstr"], c["name"]
         b.close()
+
+
+@pytest.mark.parametrize("variant", [(2, 2, 8), (4, 1, 4), (8, 1, 4), (2, 1, 8)])
+def test_skewed_exchange_lags_agree(variant, blosum62):
+    """The context hint "tag_lag" (how many rows wave w of a pair runs behind wave w-1; 0 = the synchronous per-row exchange)
+    changes no cell: every lag against the oracle on a ragged batch that includes pairs shorter than the lag and pairs whose
+    last columns leave the later waves empty."""
+    alpha, table = blosum62
+    nw, r, x = variant
+    cap = 64 * x * nw * r - 2
+    qs, ts = [], []
+    for n, (ql, tl) in enumerate([(90, cap), (3, cap - 1), (1, 40), (37, cap - 255), (64, 64 * x * r + 1), (5, 7), (0, 0), (130, cap // 2)]):
+        q, t = random_pair(43000 + n, ql, tl)
+        if n == 0:
+            t = (q * (tl // max(len(q), 1) + 1))[:tl]         # repeats of the query: long diagonals crossing the wave boundaries
+        qs.append(q)
+        ts.append(t)
+    want = {}
+    for mode in (3, 4):
+        for p, (q, t) in enumerate(zip(qs, ts)):
+            S = orc.sim_submatrix(q, t, alpha, table)
+            want[(mode, p)] = orc.dp_build(S, orc.Gap(mode, 11, 1))
+    ctx = gpu_util.ctx()
+    for lag in (0, 1, 2, 4):
+        for mode in (3, 4):
+            b = aln_amd.Batch(ctx, qs, ts)
+            with ctx.hints(dp_variant_nw=nw, dp_variant_r=r, dp_variant_x=x, tag_lag=lag):
+                b.dp_submatrix(alpha, table, mode, 11, 1, aln_amd.FWD, aln_amd.DP_FAST)
+            assert "dp_affine_tag" in b.kernel_name() and "NW=%d,R=%d" % (nw, r) in b.kernel_name()
+            for p in range(len(qs)):
+                rc, D0, PQ0, PT0 = want[(mode, p)]
+                D, PQ, PT = b.get_cells(p)
+                assert np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (variant, lag, mode, p)
+                assert np.array_equal(PQ, PQ0) and np.array_equal(PT, PT0), (variant, lag, mode, p)
+            b.close()

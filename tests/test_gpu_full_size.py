@@ -142,8 +142,10 @@ def test_c4_enumerate_all_at_full_size(blosum62):
     flags = make_subopt_regions(2002, 10)
     assert "".join(str(int(x)) for x in flags) == doc()["c2"]["flags"]
     K = 258
+    # the reference creates 5-9 thousand alignments (10-19 M list elements) per homolog pair at DELTA_RATIO 0.01 before sortSet keeps
+    # 256 (oracle/_ref `cwcount`): 16 Mi trie nodes and 32 Ki alignments per pair are enough; 0.05 overflows any pool (and the reference)
     for delta_key in ("0.01", "0.005"):
-        n_out, scores, lengths, pairs, status = b.enumerate_all("cw", 256, float(delta_key), flags, K=K, node_cap=1 << 21, ali_cap=1 << 16)
+        n_out, scores, lengths, pairs, status = b.enumerate_all("cw", 256, float(delta_key), flags, K=K, node_cap=1 << 24, ali_cap=1 << 15)
         assert (status == 0).all(), status
         for k, p in enumerate(idx):
             if p in gold:
@@ -155,7 +157,7 @@ def test_c4_enumerate_all_at_full_size(blosum62):
                 for a, e in enumerate(one):
                     assert bits(e["score"]) == bits(scores[k, a]) and np.array_equal(e["pairs"], pairs[k, a, :lengths[k, a]]), (k, a)
     # SURVEY's DELTA_RATIO 0.05: the reference finishes only the non-homolog pairs; the homologs overflow the per-pair pools
-    n_out, scores, lengths, pairs, status = b.enumerate_all("cw", 256, 0.05, flags, K=K, node_cap=1 << 21, ali_cap=1 << 16,
+    n_out, scores, lengths, pairs, status = b.enumerate_all("cw", 256, 0.05, flags, K=K, node_cap=1 << 24, ali_cap=1 << 15,
                                                             raise_on_overflow=False)
     for k, p in enumerate(idx):
         if p in gold:
