@@ -18,7 +18,8 @@ FWD, REV = 1, 2
 GAP_AFFINE_CONST, GAP_AFFINE_TPOS_MIN, GAP_DEL_TABLE_INS_TPOS, GAP_TABLES = 0, 1, 2, 3
 SIM_SUBMATRIX, SIM_MATRIX, SIM_HMAP2 = 0, 1, 2
 DP_AUTO, DP_EXACT, DP_FAST = 0, 1, 2
-ENUM_CW, ENUM_UCW, ENUM_KSCW = 0, 1, 2
+ENUM_CW, ENUM_UCW, ENUM_KSCW, ENUM_CRCW = 0, 1, 2, 3
+_ENUM = {"cw": ENUM_CW, "ucw": ENUM_UCW, "kscw": ENUM_KSCW, "crcw": ENUM_CRCW}
 
 E_BOUNDS, E_GAPSTYLE, E_STARTPAIR, E_RESIDUE, E_ARG, E_HIP, E_NOMEM, E_TOO_LONG, E_NOT_INTEGRAL, E_STATE, E_OVERFLOW = range(-1, -12, -1)
 
@@ -53,7 +54,8 @@ class AlnSim(C.Structure):
 
 class AlnNoa(C.Structure):
     _fields_ = [("kind", C.c_int32), ("number_suboptimal", C.c_int32), ("delta_ratio", C.c_float), ("user_limit", C.c_uint32),
-                ("n_existing", C.c_int32), ("existing_scores", _fp), ("k_limit", C.c_uint32)]
+                ("n_existing", C.c_int32), ("existing_scores", _fp), ("k_limit", C.c_uint32), ("sort_limit", C.c_uint32),
+                ("max_overlap", C.c_float)]
 
 
 class AlnAlignment(C.Structure):
@@ -64,7 +66,7 @@ EXPORTS = [
     "aln_ctx_create", "aln_ctx_destroy", "aln_error_string", "aln_last_error", "aln_ctx_synchronize", "aln_has_gfx950",
     "aln_batch_create", "aln_batch_destroy", "aln_batch_n_pairs", "aln_batch_device_bytes", "aln_batch_dp",
     "aln_batch_reevaluate", "aln_batch_dp_kernel_name", "aln_batch_dp_sub", "aln_batch_get_cells", "aln_batch_get_sim",
-    "aln_batch_get_corner_scores", "aln_batch_optimal", "aln_batch_optimal_enqueue", "aln_batch_optimal_collect", "aln_batch_optimal_subali", "aln_batch_enumerate", "aln_batch_enumerate_all", "aln_batch_last_enum_ms", "aln_identity",
+    "aln_batch_get_corner_scores", "aln_batch_optimal", "aln_batch_optimal_enqueue", "aln_batch_optimal_collect", "aln_batch_optimal_subali", "aln_batch_enumerate", "aln_batch_enumerate_all", "aln_batch_last_enum_ms", "aln_batch_last_enum_usage", "aln_identity",
     "aln_gapped_length", "aln_gapped_strings", "aln_hmap2_gap_arrays", "aln_score_all_vs_all", "aln_batch_last_dp_ms", "aln_batch_dp_ms_history", "aln_batch_dp_algorithmic_bytes", "aln_batch_cells",
     "aln_batch_optimal_strings", "aln_ctx_set_hint", "aln_ctx_get_hint", "aln_batch_dp_contract_bytes", "aln_batch_plane_bytes_per_cell",
     "aln_deal_units", "aln_comm_unique_id", "aln_comm_create", "aln_ctx_create_multi", "aln_comm_destroy", "aln_comm_n_ranks",
@@ -122,6 +124,7 @@ def lib():
         L.aln_batch_enumerate_all.argtypes = [C.c_void_p, C.POINTER(AlnNoa), C.POINTER(C.c_uint8), C.c_int32, C.c_uint32, C.c_uint32,
                                               C.c_int32, _ip, _fp, _ip, _ip, C.c_int32, _ip]
         L.aln_batch_last_enum_ms.argtypes = [C.c_void_p, _fp, _fp]
+        L.aln_batch_last_enum_usage.argtypes = [C.c_void_p, _ip, _ip]
         L.aln_identity.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, _ip, C.c_int32]
         L.aln_gapped_length.argtypes = [C.c_int32, C.POINTER(AlnAlignment), C.c_int32, _ip]
         L.aln_gapped_strings.argtypes = [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(AlnAlignment), C.c_int32, _ip,
@@ -420,12 +423,12 @@ class Batch:
         return s
 
     def enumerate(self, p, kind, number_suboptimal, delta_ratio, flags=None, user_limit=0, max_alignments=None, pairs_capacity=None,
-                  k_limit=0):
-        """ConstrainedNearOptimal ("cw") / UnconstrainedNearOptimal ("ucw") / KSConstrainedNearOptimal ("kscw") for pair p
-        -> list of dicts in set order."""
+                  k_limit=0, sort_limit=0, max_overlap=0.30):
+        """ConstrainedNearOptimal ("cw") / UnconstrainedNearOptimal ("ucw") / KSConstrainedNearOptimal ("kscw") /
+        CRConstrainedNearOptimal ("crcw") for pair p -> list of dicts in set order."""
         Q, T = self.dims(p)
-        noa = AlnNoa({"cw": ENUM_CW, "ucw": ENUM_UCW, "kscw": ENUM_KSCW}[kind], int(number_suboptimal), float(np.float32(delta_ratio)),
-                     int(user_limit), -1, None, int(k_limit))
+        noa = AlnNoa(_ENUM[kind], int(number_suboptimal), float(np.float32(delta_ratio)),
+                     int(user_limit), -1, None, int(k_limit), int(sort_limit), float(np.float32(max_overlap)))
         if max_alignments is None:
             max_alignments = max(int(number_suboptimal), 1) + 2
         if pairs_capacity is None:
@@ -447,11 +450,11 @@ class Batch:
         return res
 
     def enumerate_all(self, kind, number_suboptimal, delta_ratio, flags=None, K=None, user_limit=0, node_cap=0, ali_cap=0,
-                      want_pairs=True, raise_on_overflow=True, k_limit=0):
+                      want_pairs=True, raise_on_overflow=True, k_limit=0, sort_limit=0, max_overlap=0.30):
         """aln_batch_enumerate_all: every pair of the batch in one launch.  flags: None, one shared row, or an
         [n, stride] uint8 array.  -> n_out[n], scores[n,K], lengths[n,K], pairs[n,K,stride,2] or None, status[n]"""
-        noa = AlnNoa({"cw": ENUM_CW, "ucw": ENUM_UCW, "kscw": ENUM_KSCW}[kind], int(number_suboptimal), float(np.float32(delta_ratio)),
-                     int(user_limit), -1, None, int(k_limit))
+        noa = AlnNoa(_ENUM[kind], int(number_suboptimal), float(np.float32(delta_ratio)),
+                     int(user_limit), -1, None, int(k_limit), int(sort_limit), float(np.float32(max_overlap)))
         if K is None:
             K = max(int(number_suboptimal), 1) + 2
         fl, fstride = None, 0
@@ -472,6 +475,13 @@ class Batch:
         if rc != 0 and (raise_on_overflow or rc != E_OVERFLOW):
             _check(rc, self.ctx.h)
         return n_out, scores, lengths, pairs, status
+
+    def last_enum_usage(self):
+        """-> alignments created, trie nodes used, per pair, by the last enumerate_all (also for overflowed pairs)"""
+        a = np.zeros(self.n, dtype=np.int32)
+        nd = np.zeros(self.n, dtype=np.int32)
+        _check(lib().aln_batch_last_enum_usage(self.h, _i(a), _i(nd)), self.ctx.h)
+        return a, nd
 
     def last_enum_ms(self):
         a, b = C.c_float(0), C.c_float(0)

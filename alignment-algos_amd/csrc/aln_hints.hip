@@ -32,6 +32,7 @@ const HintDef kDefs[] = {
     {"exact_literal", "ALN_EXACT_LITERAL", false, &aln_hints::exact_literal},
     {"exact_alt_prio", "ALN_EXACT_ALT_PRIO", false, &aln_hints::exact_alt_prio},
     {"score_packed", "ALN_SCORE_NO_PACKED", true, &aln_hints::score_packed},
+    {"enum_pool_retries", "ALN_ENUM_POOL_RETRIES", false, &aln_hints::enum_pool_retries},
 };
 
 }  // namespace

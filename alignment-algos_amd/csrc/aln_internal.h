@@ -60,7 +60,10 @@ struct aln_hints {
   int key16 = 1;             // 0: never use the 16-bit key layout
   int tag_alt_prio = 1;      // tagged kernel: alternate s_setprio per row by hardware-slot parity (pays on lone launches; a caller that
                              // overlaps launches of several contexts sets 0)
-  int tag_lag = 4;           // tagged kernel: rows wave w runs behind wave w-1 (skewed exchange, one barrier every tag_lag rows); 0 = synchronous
+  int tag_lag = 0;           // tagged kernel: rows wave w runs behind wave w-1 (skewed exchange, one barrier every tag_lag rows); 0 = the
+                             // synchronous per-row exchange.  Measured on MI355X (config 2, lone launches): lag 0 3.11 ms, 1: 3.20, 2: 3.10,
+                             // 4: 3.28; four overlapping streams 2.82 vs 3.38 — the waves of a pair drifting apart costs more in HBM
+                             // row locality (the two halves of a plane row are written rows apart) than the barrier chain it removes
   int tag_persistent = 1;    // tagged kernel: persistent workgroups that pull pairs from a queue (0: one workgroup per pair)
   int dp_nw = 0, dp_r = 0, dp_x = 0;   // force a row-sweep variant (waves per pair, groups per lane, columns per lane and group); 0 = auto
   int exact_tiles = 1;       // 0: dp_exact_blocked instead of dp_exact_tiled where both apply
@@ -68,6 +71,7 @@ struct aln_hints {
   int exact_alt_prio = 1;    // tiled exact kernel: priority rotation over the 4 resident waves
   int score_packed = 1;      // 0: one query per wave in aln_score_all_vs_all
   int64_t enum_node_cap = 0; // trie nodes of aln_batch_enumerate (0 = default)
+  int enum_pool_retries = 2; // aln_batch_enumerate_all: times a pair whose pools overflowed is searched again with 4 x the capacity
 };
 
 struct aln_comm;
@@ -121,6 +125,7 @@ struct aln_batch {
   hipEvent_t ring0[kEvRing] = {}, ring1[kEvRing] = {};
   long n_builds = 0;
   float enum_search_ms = 0.f, enum_unroll_ms = 0.f;   // last aln_batch_enumerate_all
+  std::vector<int32_t> enum_usage;                    // ... and what every pair's search used of its pools
   // aln_batch_optimal_enqueue / _collect: two pinned result slots
   aln::PairResult* h_slot[2] = {nullptr, nullptr};
   hipEvent_t slot_ev[2] = {nullptr, nullptr};

@@ -21,10 +21,17 @@ struct EnumArgs {
   int32_t* out;         // [0] = set size, [1] = nodes used, [2] = status
   // batched launches (one block per pair): block b works on pair pair0 + b with the b-th slice of every pool
   int flags_stride;     // bytes between two pairs' flag rows (0: every pair shares one row)
+  const int32_t* pair_list;   // block b works on pair pair_list[b] (nullptr: pair0 + b)
   // KSConstrainedNearOptimal only
   uint32_t k_limit;     // NOaliParams::k_limit: operations a branch node may keep
   int32_t* uid;         // uid of every alignment (kscw.h:121,262)
   uint32_t cand_cap;    // capacity of the LDS candidate arrays
+  // CRConstrainedNearOptimal only
+  uint32_t sort_limit;  // NOaliParams::sort_limit: operations a branch node sorts and follows (<= 512)
+  float max_overlap;    // NOaliParams::max_overlap
+  uint16_t* cr_ali;     // [sort_limit][cr_tpad]: query position per template position of every operation's sub-path (0xFFFF = none)
+  int32_t* cr_reg;      // [cr_tpad]: reg[t] = region of template position t (t >= 1), reg[0] = the origin's own region
+  int cr_tpad;
 };
 
 constexpr uint32_t kNoNode = 0xFFFFFFFFu;

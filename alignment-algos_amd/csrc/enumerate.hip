@@ -23,13 +23,13 @@ __global__ __launch_bounds__(64) void enumerate_kernel(const PairDesc* __restric
                                                        const float* __restrict__ tgi, const float* __restrict__ tge,
                                                        const float* __restrict__ Hbase, const uint32_t* __restrict__ Pbase,
                                                        const float* __restrict__ Sbase, EnumArgs a) {
-  pair += (int)blockIdx.x;
   {
-    const size_t bi = blockIdx.x;
+    const size_t bi = blockIdx.x;                 // position inside the group: every pool is sliced by it
+    pair = a.pair_list ? a.pair_list[bi] : pair + (int)bi;
     a.node_pair += bi * a.node_cap; a.node_next += bi * a.node_cap;
     a.head += bi * a.ali_cap; a.score += bi * a.ali_cap;
     a.stack += bi * (size_t)a.stack_cap * kFrameWords;
-    a.flags += bi * (size_t)a.flags_stride;
+    a.flags += (size_t)(a.pair_list ? pair : (int)bi) * (size_t)a.flags_stride;   // flag rows are indexed by the pair's place in the batch
     a.out += bi * 4;
   }
   const PairDesc pd = pairs[pair];
@@ -309,6 +309,10 @@ __global__ void enumerate_ks_kernel(const PairDesc* __restrict__ pairs, int pair
                                     const uint8_t* __restrict__ tcodes, const float* __restrict__ tgi, const float* __restrict__ tge,
                                     const float* __restrict__ Hbase, const uint32_t* __restrict__ Pbase,
                                     const float* __restrict__ Sbase, EnumArgs a);
+__global__ void enumerate_cr_kernel(const PairDesc* __restrict__ pairs, int pair, EvalDev proto, const uint8_t* __restrict__ qcodes,
+                                    const uint8_t* __restrict__ tcodes, const float* __restrict__ tgi, const float* __restrict__ tge,
+                                    const float* __restrict__ Hbase, const uint32_t* __restrict__ Pbase,
+                                    const float* __restrict__ Sbase, EnumArgs a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -329,13 +333,23 @@ uint32_t default_user_limit(const aln_noa* noa) {
   if (noa->user_limit) return noa->user_limit;
   return noa->kind == ALN_ENUM_CW ? 1000000u : 100000u;
 }
+bool pruned_kind(int kind) { return kind == ALN_ENUM_KSCW || kind == ALN_ENUM_CRCW; }
+// CRCW's own parameters (NOaliParams::sort_limit 100, max_overlap 0.30: noalib.cpp:18,21); false: not usable
+bool set_cr_params(EnumArgs& a, const aln_noa* noa, int maxT) {
+  a.sort_limit = noa->sort_limit ? noa->sort_limit : 100u;
+  a.max_overlap = noa->max_overlap;
+  a.cr_tpad = (maxT + 7) & ~7;
+  return a.sort_limit >= 1 && a.sort_limit <= 512 && a.k_limit >= 1;
+}
+size_t cr_lds_bytes(const EnumArgs& a) { return (size_t)a.cand_cap * 8 + (size_t)a.sort_limit * 9 * 4; }
 }  // namespace
 
 extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* noa, const uint8_t* flags, aln_alignment* out,
                                    int32_t max_alignments, int32_t* pairs, int64_t pairs_capacity, int32_t* n_out) {
   if (!b || !noa || !out || !pairs || !n_out || pair < 0 || pair >= b->n_pairs) return ALN_E_ARG;
   if (!b->have_dp || b->have_sub || b->direction != ALN_FWD) return ALN_E_STATE;
-  const bool ks = noa->kind == ALN_ENUM_KSCW;
+  const bool ks = pruned_kind(noa->kind);      // the pruned enumerators share the frame layout and the uid array
+  const bool cr = noa->kind == ALN_ENUM_CRCW;
   if ((noa->kind == ALN_ENUM_CW || ks) && !flags) return ALN_E_ARG;
   if (noa->kind != ALN_ENUM_CW && noa->kind != ALN_ENUM_UCW && !ks) return ALN_E_ARG;
   aln_ctx* ctx = b->ctx;
@@ -371,9 +385,11 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   a.node_cap = 48u << 20;
   if (ctx->hints.enum_node_cap > 0) a.node_cap = (uint32_t)ctx->hints.enum_node_cap;
   a.stack_cap = (uint32_t)(d.Q + d.T + 8);
+  if (cr && !set_cr_params(a, noa, d.T)) return ALN_E_ARG;
   uint8_t* d_flags = nullptr; int32_t* d_out = nullptr;
   auto cleanup = [&]() {
     hipFree(a.node_pair); hipFree(a.node_next); hipFree(a.head); hipFree(a.score); hipFree(a.stack); hipFree(a.uid);
+    hipFree(a.cr_ali); hipFree(a.cr_reg);
     hipFree(d_flags); hipFree(d_out);
   };
 #define ETRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup(); return ALN_E_HIP; } } while (0)
@@ -383,6 +399,10 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   ETRY(hipMalloc((void**)&a.score, (size_t)a.ali_cap * 4));
   ETRY(hipMalloc((void**)&a.stack, (size_t)a.stack_cap * (ks ? 8 + 4 * a.k_limit : kFrameWords) * 4));
   if (ks) ETRY(hipMalloc((void**)&a.uid, (size_t)a.ali_cap * 4));
+  if (cr) {
+    ETRY(hipMalloc((void**)&a.cr_ali, (size_t)a.sort_limit * a.cr_tpad * 2));
+    ETRY(hipMalloc((void**)&a.cr_reg, (size_t)a.cr_tpad * 4));
+  }
   ETRY(hipMalloc((void**)&d_flags, (size_t)d.T));
   ETRY(hipMalloc((void**)&d_out, 16));
   if (flags) ETRY(hipMemcpyAsync(d_flags, flags, (size_t)d.T, hipMemcpyHostToDevice, ctx->stream));
@@ -400,7 +420,11 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   proto.tcn = b->d_tcn; proto.deltab = b->d_deltab; proto.deltab_off = b->d_deltab_off; proto.instab = b->d_instab;
   const bool sub = b->sim_kind == ALN_SIM_SUBMATRIX;
   const bool tpos = b->gapdev.model != ALN_GAP_AFFINE_CONST;
-  if (ks)
+  if (cr)
+    hipLaunchKernelGGL(enumerate_cr_kernel, dim3(1), dim3(64), cr_lds_bytes(a), ctx->stream, b->d_pairs, pair, proto,
+                       sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr,
+                       b->d_H, b->d_P, sub ? nullptr : b->d_S, a);
+  else if (ks)
     hipLaunchKernelGGL(enumerate_ks_kernel, dim3(1), dim3(64), (size_t)a.cand_cap * 8, ctx->stream, b->d_pairs, pair, proto,
                        sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr,
                        b->d_H, b->d_P, sub ? nullptr : b->d_S, a);
@@ -502,16 +526,19 @@ namespace aln {
 // (taken from the traceback list, which is stored end -> start), otherwise a trie walk.
 __global__ __launch_bounds__(64) void enum_unroll_all_kernel(const uint32_t* __restrict__ node_pair, const uint32_t* __restrict__ node_next,
                                                              const uint32_t* __restrict__ head, uint32_t node_cap, uint32_t ali_cap,
-                                                             const int32_t* __restrict__ sel, int K, const int32_t* __restrict__ path,
+                                                             const int32_t* __restrict__ sel, int K, const int32_t* __restrict__ pair_list,
+                                                             const int32_t* __restrict__ path,
                                                              int path_stride, const PairResult* __restrict__ res,
                                                              int32_t* __restrict__ out_pairs, int32_t* __restrict__ out_n, int stride) {
+  // blockIdx.y = position of the pair inside its group (pools, sel and outputs are group-local); gp = its index in the batch
   const int p = blockIdx.y, k = blockIdx.x;
+  const int gp = pair_list[p];
   const int idx = sel[(size_t)p * K + k];
   int32_t* o = out_pairs ? out_pairs + ((size_t)p * K + k) * stride * 2 : nullptr;
   if (idx < 0) { if (threadIdx.x == 0) out_n[(size_t)p * K + k] = 0; return; }
   if (idx == 0) {
-    const int n = res[p].n_path;
-    const int32_t* src = path + (size_t)p * path_stride * 2;
+    const int n = res[gp].n_path;
+    const int32_t* src = path + (size_t)gp * path_stride * 2;
     if (o) for (int i = threadIdx.x; i < n && i < stride; i += 64) { o[2 * i] = src[2 * (n - 1 - i)]; o[2 * i + 1] = src[2 * (n - 1 - i) + 1]; }
     if (threadIdx.x == 0) out_n[(size_t)p * K + k] = n;
     return;
@@ -535,7 +562,8 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
                                        int32_t* lengths, int32_t* pairs, int32_t pair_stride, int32_t* status) {
   if (!b || !noa || !n_out || !scores || !lengths || !status || K <= 0) return ALN_E_ARG;
   if (!b->have_dp || b->have_sub || b->direction != ALN_FWD) return ALN_E_STATE;
-  const bool ks = noa->kind == ALN_ENUM_KSCW;
+  const bool ks = pruned_kind(noa->kind);
+  const bool cr = noa->kind == ALN_ENUM_CRCW;
   if ((noa->kind == ALN_ENUM_CW || ks) && !flags) return ALN_E_ARG;
   if (noa->kind != ALN_ENUM_CW && noa->kind != ALN_ENUM_UCW && !ks) return ALN_E_ARG;
   if (pairs && pair_stride < b->path_stride) return ALN_E_ARG;
@@ -546,37 +574,39 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   // every set starts with the pair's Optimal alignment (aa_ali.cpp:83)
   int rc = launch_traceback(b, false);
   if (rc) return rc;
-  const uint32_t user_limit = default_user_limit(noa);
-  EnumArgs a = {};
-  a.kind = noa->kind; a.user_limit = user_limit; a.delta_ratio = noa->delta_ratio; a.first_slot = 1;
-  a.k_limit = ks ? (noa->k_limit ? noa->k_limit : 16u) : 0u;
-  if (a.k_limit > 64u) return ALN_E_ARG;
-  a.cand_cap = (uint32_t)(b->maxQ + b->maxT);
-  a.ali_cap = ali_cap_per_pair ? ali_cap_per_pair : 65536u;
-  a.node_cap = node_cap_per_pair ? node_cap_per_pair : (1u << 20);
-  a.stack_cap = (uint32_t)(b->maxQ + b->maxT + 8);
-  a.ptr_mode = b->ptr_mode; a.h_mode = b->h_mode;
-  a.flags_stride = flags ? flags_stride : 0;
-  uint8_t* d_flags = nullptr; int32_t *d_out = nullptr, *d_sel = nullptr, *d_lists = nullptr, *d_lens = nullptr;
+  EnumArgs a0 = {};
+  a0.kind = noa->kind; a0.user_limit = default_user_limit(noa); a0.delta_ratio = noa->delta_ratio; a0.first_slot = 1;
+  a0.k_limit = ks ? (noa->k_limit ? noa->k_limit : 16u) : 0u;
+  if (a0.k_limit > 64u) return ALN_E_ARG;
+  a0.cand_cap = (uint32_t)(b->maxQ + b->maxT);
+  a0.stack_cap = (uint32_t)(b->maxQ + b->maxT + 8);
+  a0.ptr_mode = b->ptr_mode; a0.h_mode = b->h_mode;
+  a0.flags_stride = flags ? flags_stride : 0;
+  if (cr && !set_cr_params(a0, noa, b->maxT)) return ALN_E_ARG;
+  const size_t frame_words = ks ? 8 + 4 * a0.k_limit : kFrameWords;
+
+  uint8_t* d_flags = nullptr;
   hipEvent_t evs[4] = {nullptr, nullptr, nullptr, nullptr};
+  // buffers of one group of pairs (see below)
+  EnumArgs a = a0;
+  int32_t *d_out = nullptr, *d_sel = nullptr, *d_lists = nullptr, *d_lens = nullptr, *d_list = nullptr;
+  auto free_group = [&]() {
+    hipFree(a.node_pair); hipFree(a.node_next); hipFree(a.head); hipFree(a.score); hipFree(a.stack); hipFree(a.uid);
+    hipFree(a.cr_ali); hipFree(a.cr_reg);
+    hipFree(d_out); hipFree(d_sel); hipFree(d_lists); hipFree(d_lens); hipFree(d_list);
+    a.node_pair = a.node_next = a.head = nullptr; a.score = nullptr; a.stack = nullptr; a.uid = nullptr; a.cr_ali = nullptr; a.cr_reg = nullptr;
+    d_out = d_sel = d_lists = d_lens = d_list = nullptr;
+  };
   auto cleanup = [&]() {
-    hipFree(a.node_pair); hipFree(a.node_next); hipFree(a.head); hipFree(a.score); hipFree(a.stack); hipFree(a.uid); hipFree(d_flags);
-    hipFree(d_out); hipFree(d_sel); hipFree(d_lists); hipFree(d_lens);
+    free_group();
+    hipFree(d_flags);
     for (auto ev : evs) if (ev) hipEventDestroy(ev);
   };
 #define BTRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup(); return ALN_E_HIP; } } while (0)
-  BTRY(hipMalloc((void**)&a.node_pair, (size_t)n * a.node_cap * 4));
-  BTRY(hipMalloc((void**)&a.node_next, (size_t)n * a.node_cap * 4));
-  BTRY(hipMalloc((void**)&a.head, (size_t)n * a.ali_cap * 4));
-  BTRY(hipMalloc((void**)&a.score, (size_t)n * a.ali_cap * 4));
-  BTRY(hipMalloc((void**)&a.stack, (size_t)n * a.stack_cap * (ks ? 8 + 4 * a.k_limit : kFrameWords) * 4));
-  if (ks) BTRY(hipMalloc((void**)&a.uid, (size_t)n * a.ali_cap * 4));
   const size_t fl_bytes = flags ? (flags_stride ? (size_t)n * flags_stride : (size_t)b->maxT) : (size_t)b->maxT;
   BTRY(hipMalloc((void**)&d_flags, fl_bytes));
-  BTRY(hipMalloc((void**)&d_out, (size_t)n * 16));
   if (flags) BTRY(hipMemcpyAsync(d_flags, flags, fl_bytes, hipMemcpyHostToDevice, ctx->stream));
   else BTRY(hipMemsetAsync(d_flags, 1, fl_bytes, ctx->stream));
-  a.flags = d_flags; a.out = d_out;
   EvalDev proto = {};
   proto.model = b->gapdev.model; proto.align_type = b->gapdev.align_type;
   proto.gi = b->gapdev.gi; proto.ge = b->gapdev.ge;
@@ -586,62 +616,142 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   const bool sub = b->sim_kind == ALN_SIM_SUBMATRIX;
   const bool tpos = b->gapdev.model != ALN_GAP_AFFINE_CONST;
   for (auto& ev : evs) BTRY(hipEventCreate(&ev));
-  BTRY(hipEventRecord(evs[0], ctx->stream));
-  if (ks)
-    hipLaunchKernelGGL(enumerate_ks_kernel, dim3(n), dim3(64), (size_t)a.cand_cap * 8, ctx->stream, b->d_pairs, 0, proto,
-                       sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr,
-                       b->d_H, b->d_P, sub ? nullptr : b->d_S, a);
-  else
-    hipLaunchKernelGGL(enumerate_kernel, dim3(n), dim3(64), 0, ctx->stream, b->d_pairs, 0, proto, sub ? b->d_qcodes : nullptr,
-                       sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr, b->d_H, b->d_P,
-                       sub ? nullptr : b->d_S, a);
-  BTRY(hipGetLastError());
-  BTRY(hipEventRecord(evs[1], ctx->stream));
-  std::vector<int32_t> hout((size_t)n * 4);
   std::vector<PairResult> res(n);
-  BTRY(hipMemcpyAsync(hout.data(), d_out, hout.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
   BTRY(hipMemcpyAsync(res.data(), b->d_res, sizeof(PairResult) * n, hipMemcpyDeviceToHost, ctx->stream));
   BTRY(hipStreamSynchronize(ctx->stream));
-  // per pair: sortSet on (score, index) keys, pick the survivors
-  std::vector<int32_t> sel((size_t)n * K, -1);
+  b->enum_usage.assign((size_t)n * 4, 0);
+  b->enum_search_ms = b->enum_unroll_ms = 0.f;
+  for (int p = 0; p < n; ++p) { status[p] = 0; n_out[p] = 0; }
+
+  // The search runs for GROUPS of pairs, one workgroup per pair, each with its own slice of the pools.  Round 0 is every pair
+  // with the caller's capacities.  A near-optimal search can need anything between nothing (an unrelated pair) and tens of
+  // millions of trie nodes (a 2000-residue homolog at DELTA_RATIO 0.01: 2-21 M), so pairs whose node or alignment pool
+  // overflowed are searched again, in groups sized to a device-memory budget, with four times the capacity — up to
+  // enum_pool_retries times (context hint, default 2: 16 x the caller's capacities).
+  const size_t kPoolBudget = (size_t)48 << 30;                       // bytes of pools of one group
+  std::vector<int32_t> todo((size_t)n);
+  for (int p = 0; p < n; ++p) todo[p] = p;
+  uint32_t node_cap = node_cap_per_pair ? node_cap_per_pair : (1u << 20);
+  uint32_t ali_cap = ali_cap_per_pair ? ali_cap_per_pair : 65536u;
+  std::vector<int32_t> hout, sel, hlens, hlists;
   std::vector<float> sc;
-  int worst = ALN_OK;
-  for (int p = 0; p < n; ++p) {
-    status[p] = hout[4 * p + 2] ? hout[4 * p + 2] : res[p].status;
-    n_out[p] = 0;
-    if (status[p] != 0) { worst = status[p]; continue; }
-    const int n_as = hout[4 * p];
-    sc.resize(n_as);
-    BTRY(hipMemcpy(sc.data() + 1, a.score + (size_t)p * a.ali_cap + 1, (size_t)(n_as - 1) * 4, hipMemcpyDeviceToHost));
-    sc[0] = b->islocal ? res[p].best : res[p].corner;
-    std::vector<SortKey> keys(n_as);
-    for (int k = 0; k < n_as; ++k) { keys[k].score = sc[k]; keys[k].idx = k; }
-    const int mx = noa->number_suboptimal;
-    if (mx >= n_as) std::sort(keys.begin(), keys.end());
-    else if (mx > 0) { std::partial_sort(keys.begin(), keys.begin() + mx, keys.end()); keys.erase(keys.begin() + mx, keys.end()); }
-    int keep = (int)keys.size();
-    if (keep > K) { status[p] = ALN_E_OVERFLOW; worst = ALN_E_OVERFLOW; keep = K; }
-    n_out[p] = keep;
-    for (int k = 0; k < keep; ++k) { sel[(size_t)p * K + k] = keys[k].idx; scores[(size_t)p * K + k] = keys[k].score; }
+  const int max_round = std::max(0, std::min(ctx->hints.enum_pool_retries, 3));
+  for (int round = 0; round <= max_round && !todo.empty(); ++round) {
+    std::vector<int32_t> again;
+    const size_t per_pair = (size_t)node_cap * 8 + (size_t)ali_cap * (ks ? 12 : 8) + (size_t)a0.stack_cap * frame_words * 4 +
+                            (pairs ? (size_t)K * pair_stride * 8 : 0) + (cr ? (size_t)a0.sort_limit * a0.cr_tpad * 2 + (size_t)a0.cr_tpad * 4 : 0);
+    size_t gmax = std::max<size_t>(1, kPoolBudget / per_pair);
+    if (round == 0) gmax = todo.size();                               // the caller sized round 0
+    for (size_t g0 = 0; g0 < todo.size(); g0 += gmax) {
+      const int gn = (int)std::min(gmax, todo.size() - g0);
+      const int32_t* ids = todo.data() + g0;
+      a = a0;
+      a.node_cap = node_cap; a.ali_cap = ali_cap;
+      BTRY(hipMalloc((void**)&a.node_pair, (size_t)gn * a.node_cap * 4));
+      BTRY(hipMalloc((void**)&a.node_next, (size_t)gn * a.node_cap * 4));
+      BTRY(hipMalloc((void**)&a.head, (size_t)gn * a.ali_cap * 4));
+      BTRY(hipMalloc((void**)&a.score, (size_t)gn * a.ali_cap * 4));
+      BTRY(hipMalloc((void**)&a.stack, (size_t)gn * a.stack_cap * frame_words * 4));
+      if (ks) BTRY(hipMalloc((void**)&a.uid, (size_t)gn * a.ali_cap * 4));
+      if (cr) {
+        BTRY(hipMalloc((void**)&a.cr_ali, (size_t)gn * a.sort_limit * a.cr_tpad * 2));
+        BTRY(hipMalloc((void**)&a.cr_reg, (size_t)gn * a.cr_tpad * 4));
+      }
+      BTRY(hipMalloc((void**)&d_out, (size_t)gn * 16));
+      BTRY(hipMalloc((void**)&d_list, (size_t)gn * 4));
+      BTRY(hipMemcpyAsync(d_list, ids, (size_t)gn * 4, hipMemcpyHostToDevice, ctx->stream));
+      a.flags = d_flags; a.out = d_out; a.pair_list = d_list;
+      BTRY(hipEventRecord(evs[0], ctx->stream));
+      if (cr)
+        hipLaunchKernelGGL(enumerate_cr_kernel, dim3(gn), dim3(64), cr_lds_bytes(a), ctx->stream, b->d_pairs, 0, proto,
+                           sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr,
+                           b->d_H, b->d_P, sub ? nullptr : b->d_S, a);
+      else if (ks)
+        hipLaunchKernelGGL(enumerate_ks_kernel, dim3(gn), dim3(64), (size_t)a.cand_cap * 8, ctx->stream, b->d_pairs, 0, proto,
+                           sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr,
+                           b->d_H, b->d_P, sub ? nullptr : b->d_S, a);
+      else
+        hipLaunchKernelGGL(enumerate_kernel, dim3(gn), dim3(64), 0, ctx->stream, b->d_pairs, 0, proto, sub ? b->d_qcodes : nullptr,
+                           sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr, b->d_H, b->d_P,
+                           sub ? nullptr : b->d_S, a);
+      BTRY(hipGetLastError());
+      BTRY(hipEventRecord(evs[1], ctx->stream));
+      hout.resize((size_t)gn * 4);
+      BTRY(hipMemcpyAsync(hout.data(), d_out, hout.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+      BTRY(hipStreamSynchronize(ctx->stream));
+      // per pair: sortSet on (score, index) keys, pick the survivors
+      sel.assign((size_t)gn * K, -1);
+      for (int g = 0; g < gn; ++g) {
+        const int p = ids[g];
+        for (int w = 0; w < 4; ++w) b->enum_usage[(size_t)p * 4 + w] = hout[4 * g + w];
+        status[p] = hout[4 * g + 2] ? hout[4 * g + 2] : res[p].status;
+        n_out[p] = 0;
+        if (status[p] == ALN_E_OVERFLOW && round < max_round &&
+            ((uint32_t)hout[4 * g + 1] >= a.node_cap - 64u || (uint32_t)hout[4 * g] >= a.ali_cap)) { again.push_back(p); continue; }
+        if (status[p] != 0) continue;
+        const int n_as = hout[4 * g];
+        sc.resize(n_as);
+        BTRY(hipMemcpy(sc.data() + 1, a.score + (size_t)g * a.ali_cap + 1, (size_t)(n_as - 1) * 4, hipMemcpyDeviceToHost));
+        sc[0] = b->islocal ? res[p].best : res[p].corner;
+        std::vector<SortKey> keys(n_as);
+        for (int k = 0; k < n_as; ++k) { keys[k].score = sc[k]; keys[k].idx = k; }
+        const int mx = noa->number_suboptimal;
+        if (mx >= n_as) std::sort(keys.begin(), keys.end());
+        else if (mx > 0) { std::partial_sort(keys.begin(), keys.begin() + mx, keys.end()); keys.erase(keys.begin() + mx, keys.end()); }
+        int keep = (int)keys.size();
+        if (keep > K) { status[p] = ALN_E_OVERFLOW; keep = K; }     // the caller's K slots are too few for this set
+        n_out[p] = keep;
+        for (int k = 0; k < keep; ++k) { sel[(size_t)g * K + k] = keys[k].idx; scores[(size_t)p * K + k] = keys[k].score; }
+      }
+      // unroll every survivor on the device
+      BTRY(hipMalloc((void**)&d_sel, sel.size() * 4));
+      BTRY(hipMalloc((void**)&d_lens, sel.size() * 4));
+      if (pairs) BTRY(hipMalloc((void**)&d_lists, sel.size() * (size_t)pair_stride * 8));
+      BTRY(hipMemcpyAsync(d_sel, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+      BTRY(hipEventRecord(evs[2], ctx->stream));
+      hipLaunchKernelGGL(enum_unroll_all_kernel, dim3(K, gn), dim3(64), 0, ctx->stream, a.node_pair, a.node_next, a.head, a.node_cap, a.ali_cap,
+                         d_sel, K, d_list, b->d_path, b->path_stride, b->d_res, d_lists, d_lens, pairs ? pair_stride : (1 << 30));
+      BTRY(hipGetLastError());
+      BTRY(hipEventRecord(evs[3], ctx->stream));
+      hlens.resize(sel.size());
+      BTRY(hipMemcpyAsync(hlens.data(), d_lens, sel.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+      if (pairs && gn == n && round == 0)      // the common case: everything in place, one copy
+        BTRY(hipMemcpyAsync(pairs, d_lists, sel.size() * (size_t)pair_stride * 8, hipMemcpyDeviceToHost, ctx->stream));
+      BTRY(hipStreamSynchronize(ctx->stream));
+      for (int g = 0; g < gn; ++g) {
+        const int p = ids[g];
+        if (std::find(again.begin(), again.end(), p) != again.end()) continue;
+        for (int k = 0; k < K; ++k) lengths[(size_t)p * K + k] = hlens[(size_t)g * K + k];
+        if (pairs && !(gn == n && round == 0))
+          BTRY(hipMemcpy(pairs + (size_t)p * K * pair_stride * 2, d_lists + (size_t)g * K * pair_stride * 2, (size_t)K * pair_stride * 8,
+                         hipMemcpyDeviceToHost));
+      }
+      float ms0 = 0.f, ms1 = 0.f;
+      BTRY(hipEventElapsedTime(&ms0, evs[0], evs[1]));
+      BTRY(hipEventElapsedTime(&ms1, evs[2], evs[3]));
+      b->enum_search_ms += ms0; b->enum_unroll_ms += ms1;
+      free_group();
+    }
+    todo.swap(again);
+    if (node_cap <= (1u << 29)) node_cap *= 4;
+    if (ali_cap <= (1u << 22)) ali_cap *= 4;
   }
-  // unroll every survivor on the device
-  BTRY(hipMalloc((void**)&d_sel, sel.size() * 4));
-  BTRY(hipMalloc((void**)&d_lens, sel.size() * 4));
-  if (pairs) BTRY(hipMalloc((void**)&d_lists, sel.size() * (size_t)pair_stride * 8));
-  BTRY(hipMemcpyAsync(d_sel, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  BTRY(hipEventRecord(evs[2], ctx->stream));
-  hipLaunchKernelGGL(enum_unroll_all_kernel, dim3(K, n), dim3(64), 0, ctx->stream, a.node_pair, a.node_next, a.head, a.node_cap, a.ali_cap,
-                     d_sel, K, b->d_path, b->path_stride, b->d_res, d_lists, d_lens, pairs ? pair_stride : (1 << 30));
-  BTRY(hipGetLastError());
-  BTRY(hipEventRecord(evs[3], ctx->stream));
-  BTRY(hipMemcpyAsync(lengths, d_lens, sel.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (pairs) BTRY(hipMemcpyAsync(pairs, d_lists, sel.size() * (size_t)pair_stride * 8, hipMemcpyDeviceToHost, ctx->stream));
-  BTRY(hipStreamSynchronize(ctx->stream));
-  BTRY(hipEventElapsedTime(&b->enum_search_ms, evs[0], evs[1]));
-  BTRY(hipEventElapsedTime(&b->enum_unroll_ms, evs[2], evs[3]));
 #undef BTRY
   cleanup();
+  int worst = ALN_OK;
+  for (int p = 0; p < n; ++p) if (status[p] != 0 && worst == ALN_OK) worst = status[p];
+  for (int p = 0; p < n; ++p) if (status[p] == ALN_E_OVERFLOW) worst = ALN_E_OVERFLOW;
   return worst;
+}
+
+extern "C" int aln_batch_last_enum_usage(aln_batch* b, int32_t* alignments, int32_t* nodes) {
+  if (!b) return ALN_E_ARG;
+  if ((int)b->enum_usage.size() != 4 * b->n_pairs) return ALN_E_STATE;
+  for (int p = 0; p < b->n_pairs; ++p) {
+    if (alignments) alignments[p] = b->enum_usage[4 * p];
+    if (nodes) nodes[p] = b->enum_usage[4 * p + 1];
+  }
+  return ALN_OK;
 }
 
 extern "C" int aln_batch_last_enum_ms(aln_batch* b, float* search_ms, float* unroll_ms) {

@@ -19,7 +19,7 @@ void run_enumeration(int kind, const NOaliParams& params, const unsigned char* f
   const int n_existing = (int)as.size();
   std::vector<float> ex(std::max(n_existing, 1));
   for (int k = 0; k < n_existing; ++k) ex[k] = as[k].score;
-  aln_noa noa;
+  aln_noa noa = aln_noa();
   noa.kind = kind;
   noa.number_suboptimal = params.number_suboptimal;
   noa.delta_ratio = params.delta_ratio;
@@ -27,6 +27,8 @@ void run_enumeration(int kind, const NOaliParams& params, const unsigned char* f
   noa.n_existing = n_existing;
   noa.existing_scores = ex.data();
   noa.k_limit = params.k_limit;
+  noa.sort_limit = params.sort_limit;
+  noa.max_overlap = params.max_overlap;
   const int per = std::min(dpm.getQuerySize(), dpm.getTemplateSize()) + 3;
   int32_t cap = std::max(params.number_suboptimal, 1) + n_existing + 1, n_out = 0;
   std::vector<aln_alignment> out;

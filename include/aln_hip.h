@@ -57,8 +57,9 @@ enum aln_dp_algo {
 enum aln_enum_kind {
   ALN_ENUM_CW = 0,              /* ConstrainedNearOptimal, cw.h:68-284 */
   ALN_ENUM_UCW = 1,             /* UnconstrainedNearOptimal, ucw.h:64-236 */
-  ALN_ENUM_KSCW = 2             /* KSConstrainedNearOptimal, kscw.h:109-351 (parity unpinned: the reference header does not
+  ALN_ENUM_KSCW = 2,            /* KSConstrainedNearOptimal, kscw.h:109-351 (parity unpinned: the reference header does not
                                    compile on LP64) */
+  ALN_ENUM_CRCW = 3             /* CRConstrainedNearOptimal, crcw.h:134-594 (parity unpinned, same reason) */
 };
 
 enum aln_status {
@@ -148,8 +149,10 @@ typedef struct {
                                    >= 0: the caller's AlignmentSet already holds this many alignments (enumerate() appends) */
   const float* existing_scores; /* their scores (they take part in sortSet); such entries come back with n_pairs = -1
                                    and pair_off = their old index */
-  uint32_t k_limit;             /* KSCW: operations a branch node keeps (NOaliParams::k_limit, default 16); its user_limit is
-                                   NOaliParams::user_limit (0 = the default 100000, noalib.cpp:20) */
+  uint32_t k_limit;             /* KSCW / CRCW: operations a branch node keeps (NOaliParams::k_limit, default 16); their user_limit
+                                   is NOaliParams::user_limit (0 = the default 100000, noalib.cpp:20) */
+  uint32_t sort_limit;          /* CRCW: operations a branch node sorts and follows (NOaliParams::sort_limit; 0 = the default 100) */
+  float max_overlap;            /* CRCW: share of an accepted sub-path a later one may repeat (NOaliParams::max_overlap, default 0.30) */
 } aln_noa;
 
 /* One alignment as the enumerators return it (AlignedPairList, alignment.h:52-113). */
@@ -173,13 +176,15 @@ int aln_ctx_synchronize(aln_ctx* ctx);
 int aln_has_gfx950(void);
 /* Tuning / kernel-selection hints of ONE context.  A context reads its defaults from the environment once, when it is created
  * (ALN_NO_TAG_KERNEL, ALN_NO_H16, ALN_NO_KEY16, ALN_TAG_ALT_PRIO, ALN_TAG_PERSISTENT, ALN_DP_VARIANT="NW,R[,X]", ALN_EXACT_NO_TILES,
- * ALN_EXACT_LITERAL, ALN_EXACT_ALT_PRIO, ALN_SCORE_NO_PACKED, ALN_ENUM_NODE_CAP); launches never read the environment.  Keys:
+ * ALN_EXACT_LITERAL, ALN_EXACT_ALT_PRIO, ALN_SCORE_NO_PACKED, ALN_ENUM_NODE_CAP, ALN_TAG_LAG, ALN_ENUM_POOL_RETRIES); launches never read the environment.  Keys:
  *   "tag_kernel" "h16" "key16"     1/0: tagged-key kernel / uint16 score plane / 16-bit key layout allowed (results identical)
  *   "tag_alt_prio"                  1/0: row-alternating wave priority in the tagged kernel (a scheduling hint; pays when launches
  *                                   follow each other on one stream, loses when launches of several contexts overlap)
  *   "tag_persistent"                1/0: persistent workgroups pulling pairs from a queue / one workgroup per pair
  *   "dp_variant_nw" "dp_variant_r" "dp_variant_x"   force a row-sweep instantiation (0 = automatic)
- *   "exact_tiles" "exact_literal" "exact_alt_prio" "score_packed" "enum_node_cap"
+ *   "exact_tiles" "exact_literal" "exact_alt_prio" "score_packed" "enum_node_cap" "tag_lag"
+ *   "enum_pool_retries"             aln_batch_enumerate_all: how often a pair whose pools overflowed is searched again with four
+ *                                   times the capacity (default 2)
  * Unknown key -> ALN_E_ARG.  No hint changes any result. */
 int aln_ctx_set_hint(aln_ctx* ctx, const char* key, int64_t value);
 int aln_ctx_get_hint(const aln_ctx* ctx, const char* key, int64_t* value);
@@ -256,8 +261,9 @@ int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* noa, const ui
  * sortSet(number_suboptimal) per pair on (score, index) keys, survivors are unrolled on the device.  Every set is
  * seeded with the pair's Optimal alignment (noa->n_existing is ignored).
  *   flags: SuboptFlags rows, pair p's row at flags + p * flags_stride (flags_stride 0: one shared row of max T bytes);
- *   node_cap_per_pair / ali_cap_per_pair: trie nodes / alignments one pair may create before ALN_E_OVERFLOW
- *   (0 = 1 Mi nodes / 64 Ki alignments);  K: slots per pair in the outputs (>= min(number_suboptimal, set size)).
+ *   node_cap_per_pair / ali_cap_per_pair: trie nodes / alignments one pair's pools hold at first (0 = 1 Mi nodes / 64 Ki
+ *   alignments); pairs that need more are searched again with 4 x larger pools, in groups sized to a device-memory budget,
+ *   "enum_pool_retries" times (context hint, default 2), and only then report ALN_E_OVERFLOW;  K: slots per pair in the outputs (>= min(number_suboptimal, set size)).
  * Outputs (slot k of pair p at index p*K + k, set order): n_out[p] = set size after sortSet, scores, lengths,
  * pairs (NULL = not wanted) as (q,t) int32 at (p*K + k) * pair_stride * 2, status[p] = 0 / ALN_E_STARTPAIR /
  * ALN_E_OVERFLOW.  Returns the worst per-pair status. */
@@ -265,6 +271,10 @@ int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const uint8_t* fla
                             uint32_t node_cap_per_pair, uint32_t ali_cap_per_pair, int32_t K,
                             int32_t* n_out, float* scores, int32_t* lengths, int32_t* pairs, int32_t pair_stride,
                             int32_t* status);
+/* What the last aln_batch_enumerate_all used of every pair's pools: alignments created before sortSet (the reference's
+ * as.size(), cw.h:91) and trie nodes — also for pairs that reported ALN_E_OVERFLOW (the count at which they stopped), so that a
+ * caller can size node_cap_per_pair / ali_cap_per_pair.  Either pointer may be NULL. */
+int aln_batch_last_enum_usage(aln_batch* b, int32_t* alignments, int32_t* nodes);
 /* Milliseconds the device spent in the search kernel / the unroll kernel of the last aln_batch_enumerate_all. */
 int aln_batch_last_enum_ms(aln_batch* b, float* search_ms, float* unroll_ms);
 

@@ -787,11 +787,203 @@ struct Enum {
       k = (int)as->size();
     }
   }
+
+  // ---- CRConstrainedNearOptimal (crcw.h:134-594): "controlled redundancy" — a branch node sorts its operations, follows each
+  // one along the stored pointers to the end of the template's current flag region, drops the operations whose sub-path shares
+  // more than max_overlap of an accepted, better one's, and recurses on the survivors (at most the node's limit). ---------
+  struct cr_op {                                           // crcw.h:47-56
+    unsigned int limit, index;
+    int q0, t0, k0;
+    float score, new_r;
+    cr_op(unsigned int l, int q, int t, int k, float s = 0.f, float n = 0.f) : limit(l), index(0), q0(q), t0(t), k0(k), score(s), new_r(n) {}
+    bool operator<(const cr_op& a) const { return score > a.score; }
+  };
+  unsigned cr_sort_limit; float cr_max_overlap;
+  std::vector<int> cr_regions;                             // crcw.h:174-179: regions[i] = flips of the flags among positions 0 .. i+1
+  std::vector<std::vector<int> > cr_ali;                   // alignments[sort_limit][t_last]
+  long cr_oob;                                             // times the reference would have read regions[-1] (crcw.h:387)
+  // The reference indexes regions[t-1] with t == 0 when a sub-path reaches the matrix origin (crcw.h:387): a read of the heap word
+  // in front of the array (UB).  With glibc that word is the chunk size, a number far above any region count, and the value is
+  // only compared for equality with other sub-paths' end states — so sub-paths ending at t == 0 form a class of their own.
+  // kOriginState stands for that class; cr_oob counts how often it was needed.
+  enum { kOriginState = -1 };
+  int cr_region_at(int t) { if (t < 1) { ++cr_oob; return kOriginState; } return cr_regions[t - 1]; }
+
+  // crcw.h:552-592
+  void force_opt_path_cr(cr_op& op) {
+    int pq = -1, pt = -1;
+    int q0 = op.q0, t0 = op.t0, k0 = op.k0;
+    while (t0 > 0 && q0 > 0) {
+      (*as)[k0].prepend(q0, t0);
+      (*as)[k0].score += S[q0 * T + t0];
+      pq = PQ[q0 * T + t0];
+      pt = PT[q0 * T + t0];
+      float g;
+      if (q0 - pq == 1) g = del(pq, q0, pt, t0);
+      else g = ins(pq, q0, pt, t0);
+      (*as)[k0].score -= g;
+      t0 = pt; q0 = pq;
+    }
+    (*as)[k0].prepend(0, 0);
+  }
+
+  // crcw.h:345-550
+  void filter_and_extend_cr(int q0, int t0, std::vector<cr_op>& v_op) {
+    const int end_alignment = 2;
+    const size_t n = v_op.size();
+    std::vector<char> filter(n);
+    std::vector<int> p_rq(n), p_rt(n), l_sp(n), state(n);
+    std::vector<float> rs(n);
+    for (size_t i = 0; i < n; ++i)                         // reinit_mem(t0, n)
+      for (int j = 0; j < t0; ++j) cr_ali[i][j] = -1;
+    for (size_t i = 0; i < n; ++i) {
+      float g;
+      int pq, pt;
+      v_op[i].index = (unsigned)i;
+      int q = v_op[i].q0;
+      int t = v_op[i].t0;
+      l_sp[i] = 1;
+      state[i] = cr_region_at(t);
+      rs[i] = v_op[i].new_r;
+      while (q > 0 && t > 0 && cr_regions[t - 1] == state[i]) {
+        cr_ali[i][t - 1] = q;
+        ++l_sp[i];
+        pq = PQ[q * T + t];
+        pt = PT[q * T + t];
+        if (q - pq == 1) g = del(pq, q, pt, t);
+        else g = ins(pq, q, pt, t);
+        rs[i] += S[q * T + t];
+        rs[i] -= g;
+        q = pq; t = pt;
+      }
+      p_rq[i] = q; p_rt[i] = t;
+      state[i] = cr_region_at(t);                          // crcw.h:387 (t may be 0 here)
+    }
+    for (size_t i = 1; i < n; ++i) filter[i] = false;
+    filter[0] = true;
+    unsigned accepted = 1;
+    const unsigned lim = v_op.back().limit;
+    for (size_t i = 1; i < n && accepted < lim; ++i) {
+      filter[i] = true;
+      for (size_t j = 0; j < i; ++j) {
+        if (filter[i] && filter[j] && state[i] == state[j]) {
+          float overlap = 0.f;
+          float overlap_max = cr_max_overlap * (float)l_sp[j];
+          if (p_rq[i] == p_rq[j] && p_rt[i] == p_rt[j]) ++overlap;
+          for (int k = t0 - 1; k >= p_rt[i]; --k) {
+            if (cr_ali[i][k] > -1 && cr_ali[j][k] > -1 && cr_ali[i][k] == cr_ali[j][k]) {
+              ++overlap;
+              if (overlap > overlap_max) { filter[i] = false; break; }
+            }
+          }
+        }
+      }
+      if (filter[i]) ++accepted;
+    }
+    std::vector<cr_op> tmp;
+    accepted = 0;
+    for (size_t i = 0; i < n && accepted < lim; ++i)
+      if (filter[i]) { tmp.push_back(v_op[i]); ++accepted; }
+    tmp.swap(v_op);
+    for (size_t i = 1; i < v_op.size(); ++i) v_op[i].limit = std::max(2u, lim / 2);
+    int k = v_op[0].k0;
+    OrcAli curr((*as)[k]);
+    for (size_t i = 0; i < v_op.size(); ++i) {
+      int oi = (int)v_op[i].index;
+      if (k == (int)as->size()) { as->push_back(curr); (*as)[k].uid = k; }
+      (*as)[k].prepend(q0, t0);
+      for (int j = t0 - 1; j > p_rt[oi]; --j) {
+        int aq = cr_ali[oi][j - 1];
+        if (aq > -1) (*as)[k].prepend(aq, j);
+      }
+      (*as)[k].score = rs[oi];
+      v_op[i].q0 = p_rq[oi];
+      v_op[i].t0 = p_rt[oi];
+      v_op[i].k0 = k;
+      if (p_rq[oi] <= end_alignment || p_rt[oi] <= end_alignment) {
+        force_opt_path_cr(v_op[i]);
+        v_op[i].k0 = -1;
+      }
+      k = (int)as->size();
+    }
+  }
+
+  // crcw.h:205-338
+  void branch_cr(cr_op& op) {
+    unsigned int k_limit = op.limit;
+    int q0 = op.q0, t0 = op.t0, k0 = op.k0;
+    if (k_limit < 2) { force_opt_path_cr(op); return; }
+    if (as->size() > user_limit) { force_opt_path_cr(op); return; }
+    if (q0 < 1 || t0 < 1) { err = ORC_E_ARG; return; }     // the reference would index row/column -1 here
+    std::vector<cr_op> all_op;
+    all_op.reserve(q0 + t0);
+    float f, r, g, sum;
+    OrcAli curr((*as)[k0]);
+    r = curr.score + S[q0 * T + t0];
+    f = d(q0 - 1, t0 - 1);
+    sum = f + r;
+    if (sum > thr) all_op.push_back(cr_op(k_limit, q0 - 1, t0 - 1, k0, sum, r));
+    for (int i = t0 - 2; i > 0; --i) {
+      f = d(q0 - 1, i);
+      g = del(q0 - 1, q0, i, t0);
+      sum = f + r - g;
+      if (sum > thr) all_op.push_back(cr_op(k_limit, q0 - 1, i, k0, sum, r - g));
+    }
+    for (int j = q0 - 2; j > 0; --j) {
+      f = d(j, t0 - 1);
+      g = ins(j, q0, t0 - 1, t0);
+      sum = f + r - g;
+      if (sum > thr) all_op.push_back(cr_op(k_limit, j, t0 - 1, k0, sum, r - g));
+    }
+    if (all_op.size() == 0) { force_opt_path_cr(op); return; }
+    if (all_op.size() > cr_sort_limit) {
+      std::partial_sort(all_op.begin(), all_op.begin() + cr_sort_limit, all_op.end());
+      all_op.erase(all_op.begin() + cr_sort_limit, all_op.end());
+    } else {
+      std::sort(all_op.begin(), all_op.end());
+    }
+    filter_and_extend_cr(q0, t0, all_op);
+    for (std::vector<cr_op>::iterator it = all_op.begin(); it != all_op.end(); ++it)
+      if (it->k0 > -1) branch_cr(*it);
+  }
 };
 
 }  // namespace
 
 extern "C" {
+
+// CRConstrainedNearOptimal::enumerate (crcw.h:134-166).  Parity UNPINNED: crcw.h does not compile on LP64 (:242, min(size_t,
+// unsigned)) and its debug operator<< ties it to Troll-dependent types; this restates the source as written, with the one
+// out-of-bounds read (regions[-1], :387) given the value it has in practice (see cr_region_at).  *oob_reads (may be NULL)
+// receives how often that read would have happened.
+int orc_enumerate_cr(int Q, int T, const float* D, const int* PQ, const int* PT, const float* S, const orc_gap* gap,
+                     const unsigned char* flags, int number_suboptimal, float delta_ratio, unsigned k_limit, unsigned sort_limit,
+                     unsigned user_limit, float max_overlap, orc_set* as, long* oob_reads) {
+  if (sort_limit < 1 || Q < 2 || T < 2) return ORC_E_ARG;
+  Enum e;
+  e.kind = 3; e.Q = Q; e.T = T; e.D = D; e.PQ = PQ; e.PT = PT; e.S = S; e.gap = gap;
+  e.flags = flags; e.as = &as->v; e.err = 0;
+  e.user_limit = user_limit;
+  e.cr_sort_limit = sort_limit; e.cr_max_overlap = max_overlap; e.cr_oob = 0;
+  int q_last = Q - 1, t_last = T - 1;
+  // init_mem (crcw.h:168-185)
+  e.cr_ali.assign(sort_limit, std::vector<int>(t_last, -1));
+  e.cr_regions.assign(t_last, 0);
+  { int state = 0; for (int i = 0; i < T - 1; ++i) { if ((flags[i + 1] != 0) != (flags[i] != 0)) ++state; e.cr_regions[i] = state; } }
+  OrcAli seed;
+  seed.uid = 1;                          // crcw.h:147
+  as->v.push_back(seed);
+  int init = (int)as->v.size() - 1;
+  float top = D[q_last * T + t_last];
+  float threshold = (1.f - delta_ratio) * top;
+  threshold = std::min(threshold, top - 0.1f);
+  e.thr = threshold;
+  Enum::cr_op op(k_limit, q_last, t_last, init);
+  e.branch_cr(op);
+  orc_set_sort(as, number_suboptimal);
+  if (oob_reads) *oob_reads = e.cr_oob;
+  return e.err;
+}
 
 // cw.h:68-92 / ucw.h:64-85
 int orc_enumerate(int kind, int Q, int T, const float* D, const int* PQ, const int* PT,

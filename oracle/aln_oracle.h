@@ -127,6 +127,14 @@ int orc_enumerate_ks(int Q, int T, const float* D, const int* PQ, const int* PT,
                      const unsigned char* flags, int number_suboptimal, float delta_ratio, unsigned k_limit, unsigned user_limit,
                      orc_set* as);
 
+/* CRConstrainedNearOptimal (crcw.h:134-594): operations sorted per branch node (at most sort_limit kept), each followed along the
+ * stored pointers to the end of the current flag region, operations sharing more than max_overlap of an accepted better one's
+ * sub-path dropped, at most the node's limit survive.  Parity unpinned (the header does not build on LP64).  *oob_reads: how
+ * often the reference would have read regions[-1] (crcw.h:387); the restatement gives that read its own state class. */
+int orc_enumerate_cr(int Q, int T, const float* D, const int* PQ, const int* PT, const float* S, const orc_gap* gap,
+                     const unsigned char* flags, int number_suboptimal, float delta_ratio, unsigned k_limit, unsigned sort_limit,
+                     unsigned user_limit, float max_overlap, orc_set* as, long* oob_reads);
+
 /* SequenceGaps (gstrings.h:84-164, gstrings.cpp:17-29): template line and one query line
  * per alignment.  Every line is orc_gapped_len() chars (+NUL); qlines is n x stride, stride > that. */
 int orc_gapped_len(const orc_set* as, int T);

@@ -226,6 +226,23 @@ def enumerate_ks(D, PQ, PT, S, gap, flags, number_suboptimal, delta_ratio, k_lim
                                   C.c_uint(user_limit), aset.h)
 
 
+def enumerate_cr(D, PQ, PT, S, gap, flags, number_suboptimal, delta_ratio, k_limit, aset, sort_limit=100, user_limit=100000,
+                 max_overlap=0.30):
+    """CRConstrainedNearOptimal (crcw.h:134-594); NOaliParams defaults k_limit 16, sort_limit 100, user_limit 100000, max_overlap 0.30
+    (noalib.cpp:15-21).  -> (status, times the reference would have read regions[-1])"""
+    Q, T = D.shape
+    fl = np.ascontiguousarray(flags if flags is not None else np.ones(T), dtype=np.uint8)
+    D = np.ascontiguousarray(D, dtype=np.float32)
+    PQ = np.ascontiguousarray(PQ, dtype=np.int32)
+    PT = np.ascontiguousarray(PT, dtype=np.int32)
+    S = np.ascontiguousarray(S, dtype=np.float32)
+    oob = C.c_long(0)
+    rc = lib().orc_enumerate_cr(Q, T, _fp(D), _ip(PQ), _ip(PT), _fp(S), gap.ref, fl.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                int(number_suboptimal), C.c_float(float(np.float32(delta_ratio))), C.c_uint(k_limit), C.c_uint(sort_limit),
+                                C.c_uint(user_limit), C.c_float(float(np.float32(max_overlap))), aset.h, C.byref(oob))
+    return rc, oob.value
+
+
 def annot(score, identity, significance=9999.0):
     """FASTA annotation of fastaio.h:79-91 (ostream default precision == %g)."""
     def g(x):

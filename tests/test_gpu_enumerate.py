@@ -227,3 +227,60 @@ def test_batched_kscw_matches_single_pair_and_oracle(blosum62):
                 assert np.array_equal(lists[p, k, :lengths[p, k]], r["pairs"]), (mode, p, k)
                 assert np.array_equal(one[k]["pairs"], r["pairs"])
         b.close()
+
+
+def test_crcw_vs_oracle(blosum62):
+    """CRConstrainedNearOptimal (crcw.h:134-594) on the device: sorted operations, sub-paths followed to the end of the flag
+    region, the overlap filter, limits, forced optimal paths — one pair at a time and the whole batch in one launch, against
+    the oracle's restatement.  Parity UNPINNED against the reference (crcw.h does not build on LP64, :242); the one
+    out-of-bounds read of the source (regions[-1], :387) is modelled as a region of its own in both (the oracle counts how
+    often it is reached: it is, on these inputs)."""
+    alpha, table = blosum62
+    rng = np.random.RandomState(31)
+    lens = [9, 24, 57, 64, 90, 130, 200, 3, 1]
+    pairs = [homolog_pair(67000 + n, ln, sub_rate=0.2, indel=3) for n, ln in enumerate(lens)]
+    maxT = max(len(t) for _, t in pairs) + 2
+    oob_total = 0
+    for mode, (gi, ge) in ((1, (11, 1)), (4, (4.73, 0.34)), (3, (11, 1))):
+        b = aln_amd.Batch(gpu_util.ctx(), [p[0] for p in pairs], [p[1] for p in pairs])
+        b.dp_submatrix(alpha, table, mode, gi, ge)
+        for rep in range(2):
+            nsub = int(rng.choice([5, 40, 300]))
+            delta = float(rng.choice([0.05, 0.1, 0.3, 0.6]))
+            klim = int(rng.choice([1, 2, 3, 4, 8, 16, 33]))
+            slim = int(rng.choice([1, 3, 10, 100]))
+            ulim = int(rng.choice([100000, 7]))
+            movl = float(rng.choice([0.0, 0.3, 0.75, 1.0]))
+            flags = np.zeros((len(pairs), maxT), dtype=np.uint8)
+            for p, (q, t) in enumerate(pairs):
+                flags[p, :len(t) + 2] = orc.make_subopt_regions(len(t) + 2, 1 + (p + rep) % 7)
+            n_out, scores, lengths, lists, status = b.enumerate_all("crcw", nsub, delta, flags, K=nsub + 2, node_cap=1 << 20, ali_cap=1 << 16,
+                                                                     k_limit=klim, sort_limit=slim, max_overlap=movl, user_limit=ulim)
+            assert (status == 0).all(), (mode, rep, status)
+            for p, (q, t) in enumerate(pairs):
+                S = orc.sim_submatrix(q, t, alpha, table)
+                gap = orc.Gap(mode, gi, ge)
+                rc, D0, PQ0, PT0 = orc.dp_build(S, gap)
+                rc2, sc, pl = orc.optimal(D0, PQ0, PT0, mode == 3)
+                s = orc.AliSet()
+                s.push(pl, sc)
+                rc3, oob = orc.enumerate_cr(D0, PQ0, PT0, S, gap, flags[p, :len(t) + 2], nsub, delta, klim, s, sort_limit=slim,
+                                            user_limit=ulim, max_overlap=movl)
+                assert rc3 == 0
+                oob_total += oob
+                s.identity(q, t)
+                what = (mode, rep, p, nsub, delta, klim, slim, ulim, movl)
+                assert n_out[p] == len(s), what + (n_out[p], len(s))
+                one = b.enumerate(p, "crcw", nsub, delta, flags[p, :len(t) + 2], user_limit=ulim, k_limit=klim, sort_limit=slim,
+                                  max_overlap=movl, max_alignments=max(nsub, len(s)) + 2)
+                assert len(one) == len(s), what
+                for k in range(len(s)):
+                    r = s.get(k)
+                    assert scores[p, k].view(np.uint32) == r["score"].view(np.uint32), what + (k,)
+                    assert np.array_equal(lists[p, k, :lengths[p, k]], r["pairs"]), what + (k,)
+                    assert np.float32(one[k]["score"]).view(np.uint32) == r["score"].view(np.uint32), what + (k,)
+                    assert one[k]["uid"] == r["uid"], what + (k, one[k]["uid"], r["uid"])
+                    assert np.array_equal(one[k]["pairs"], r["pairs"]), what + (k,)
+                    assert np.float32(one[k]["identity"]).view(np.uint32) == r["identity"].view(np.uint32)
+        b.close()
+    assert oob_total > 0
