@@ -169,7 +169,7 @@ void aln_batch_destroy(aln_batch* b) {
   if (!b) return;
   hipFree(b->d_pairs); hipFree(b->d_qcodes); hipFree(b->d_tcodes); hipFree(b->d_H); hipFree(b->d_P); hipFree(b->d_S);
   hipFree(b->d_res); hipFree(b->d_table32); hipFree(b->d_tablef); hipFree(b->d_tgi); hipFree(b->d_tge);
-  hipFree(b->d_path); hipFree(b->d_bounds); hipFree(b->d_xscratch); hipFree(b->d_tcn); hipFree(b->d_deltab); hipFree(b->d_deltab_off); hipFree(b->d_instab);
+  hipFree(b->d_path); hipFree(b->d_bounds); hipFree(b->d_xscratch); hipFree(b->d_tagq); hipFree(b->d_tagstate); hipFree(b->d_tcn); hipFree(b->d_deltab); hipFree(b->d_deltab_off); hipFree(b->d_instab);
   for (int k = 0; k < 2; ++k) { if (b->h_slot[k]) hipHostFree(b->h_slot[k]); if (b->slot_ev[k]) hipEventDestroy(b->slot_ev[k]); }
   for (int k = 0; k < aln_batch::kEvRing; ++k) { if (b->ring0[k]) hipEventDestroy(b->ring0[k]); if (b->ring1[k]) hipEventDestroy(b->ring1[k]); }
   delete b;
@@ -332,6 +332,7 @@ int run_dp(aln_batch* b, bool simplane_integral) {
     ++b->n_builds;
   }
   ALN_HIP_CHECK(ctx, hipEventRecord(b->ev0, ctx->stream));
+  b->tag_segmented = false;
   int rc = tagged ? launch_dp_affine_tag(b) : fast ? launch_dp_affine_int(b, !sub) : launch_dp_exact(b);
   if (rc) return rc;
   ALN_HIP_CHECK(ctx, hipEventRecord(b->ev1, ctx->stream));

@@ -24,7 +24,7 @@ const HintDef kDefs[] = {
     {"key16", "ALN_NO_KEY16", true, &aln_hints::key16},
     {"tag_alt_prio", "ALN_TAG_ALT_PRIO", false, &aln_hints::tag_alt_prio},
     {"tag_lag", "ALN_TAG_LAG", false, &aln_hints::tag_lag},
-    {"tag_persistent", "ALN_TAG_PERSISTENT", false, &aln_hints::tag_persistent},
+    {"tag_segments", "ALN_TAG_SEGMENTS", false, &aln_hints::tag_segments},
     {"dp_variant_nw", nullptr, false, &aln_hints::dp_nw},
     {"dp_variant_r", nullptr, false, &aln_hints::dp_r},
     {"dp_variant_x", nullptr, false, &aln_hints::dp_x},

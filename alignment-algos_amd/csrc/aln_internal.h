@@ -64,7 +64,8 @@ struct aln_hints {
                              // synchronous per-row exchange.  Measured on MI355X (config 2, lone launches): lag 0 3.11 ms, 1: 3.20, 2: 3.10,
                              // 4: 3.28; four overlapping streams 2.82 vs 3.38 — the waves of a pair drifting apart costs more in HBM
                              // row locality (the two halves of a plane row are written rows apart) than the barrier chain it removes
-  int tag_persistent = 1;    // tagged kernel: persistent workgroups that pull pairs from a queue (0: one workgroup per pair)
+  int tag_segments = 1;      // tagged kernel: (pair, row segment) work items handed out by a queue (dp_affine_tag.hip "Segment queue"):
+                             // 0 = one workgroup per pair, 1 = when the batch alone fills the GPU (>= 512 long pairs), 2 = whenever pairs are long
   int dp_nw = 0, dp_r = 0, dp_x = 0;   // force a row-sweep variant (waves per pair, groups per lane, columns per lane and group); 0 = auto
   int exact_tiles = 1;       // 0: dp_exact_blocked instead of dp_exact_tiled where both apply
   int exact_literal = 0;     // 1: the literal O(n^3) kernel everywhere
@@ -110,6 +111,9 @@ struct aln_batch {
   int32_t path_stride;
   int32_t* d_bounds;
   float* d_xscratch = nullptr; size_t xscratch_floats = 0;   // far-insertion scratch of dp_exact_blocked
+  int* d_tagq = nullptr; size_t tagq_bytes = 0;              // segment queue of dp_affine_tag (counters, error word, item slots)
+  uint32_t* d_tagstate = nullptr; size_t tagstate_bytes = 0; // ... and its hand-off slots
+  bool tag_segmented = false;                                // the last tagged launch used them
   // state of the last dp
   bool have_dp, have_sub;
   int32_t sim_kind, direction, algo, bug_b4;

@@ -46,7 +46,38 @@ struct TagParams {
   int lag;        // 0: the waves of a pair exchange their row state synchronously (write, barrier, read inside every row);
                   // L = 2^k >= 1: wave w runs L*w rows behind wave 0 and reads what the earlier waves left in a ring of
                   // exchange slots, one workgroup barrier every L rows (see "skewed exchange" below)
+  // ---- segment queue (see "Segment queue" in the kernel) ----
+  int seg_mode;   // 0: workgroup b builds pair b from its first to its last row; 1: workgroups take (pair, row segment) items
+  int n_pairs;
+  int* queue;     // [0] ticket counter, [1] push counter, [2] error word, [16 ...] item slots; every word 0xFFFFFFFF before the launch
+  uint32_t* state;   // hand-off slots: (pair * kSegs + segment) * kStateBytes
 };
+
+// Segment queue.  With one workgroup per pair a batch of 1024 pairs x 2 waves fills the 1024 SIMDs exactly once: the SIMD arbiter
+// favours its older wave, so pairs finish between 2.4 and 3.3 ms, XCDs differ by 6-7 %, and everything that finishes early
+// idles.  In segment mode a pair's interior rows are cut into kSegs consecutive segments of decreasing length (6:5:4:3:2:1) and a
+// launch has one workgroup per (pair, segment).  A workgroup takes a TICKET when it starts (atomic counter).  Tickets below
+// n_pairs mean "first segment of pair <ticket>"; every later ticket waits for the next item in a queue that finishing workgroups
+// feed: whoever completes segment s of a pair stores the pair's row state (previous row, per-column insertion maxima, scan
+// carries, running find_max) to a hand-off slot and pushes (pair, s+1).  So a freed SIMD slot continues whichever pair became
+// ready first, on whichever XCD has room, until the whole batch is done; only the last, short segments form a tail.
+// No deadlock: an item is only ever held by a workgroup that has started, it never waits once it has its item, and the k-th
+// waiting ticket needs only the k-th push, which the k-th completion of a non-final segment delivers.
+// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility; cdna_hip_programming.md Guideline 16, form R1): the state goes out
+// with write-through (sc1) 16-byte stores, every wave drains them (s_waitcnt vmcnt(0)), a workgroup barrier, then ONE lane
+// publishes the item with an agent-scope atomic store; the consumer polls that one word (relaxed, agent scope), executes one
+// agent-scope acquire, and the workgroup reads the state with sc1 loads behind a barrier.  Every hand-off slot is written once
+// and read once per launch (slot = pair x segment), so no line is rewritten while a stale copy could sit in another XCD's L2.
+constexpr int kSegs = 6;
+constexpr int kSegMinRows = 512;                       // pairs with fewer rows are one segment
+__host__ __device__ inline int seg_count(int Q) { return Q >= kSegMinRows ? kSegs : 1; }
+// first interior row of segment s (s = 0 .. n): interior rows are 2 .. Q-2; weights 6:5:4:3:2:1
+__host__ __device__ inline int seg_bound(int Q, int s, int n) {
+  if (n == 1) return s == 0 ? 2 : Q - 1;
+  const int cum[kSegs + 1] = {0, 6, 11, 15, 18, 20, 21};
+  const int rows = Q - 3 > 0 ? Q - 3 : 0;
+  return s >= n ? Q - 1 : 2 + (int)(((long)rows * cum[s]) / 21);
+}
 
 template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
 __device__ __forceinline__ int tdpp(int old, int src) {
@@ -106,8 +137,39 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
   __shared__ __attribute__((aligned(16))) int xch[RING][NW][4];
   __shared__ int red[NW][2];
 
-  const PairDesc pd = pairs[blockIdx.x];
+  // ---- which pair, which rows ------------------------------------------------------------------------------------
+  __shared__ int s_item;
+  int pair_id = blockIdx.x, seg = 0;
+  if (prm.seg_mode) {
+    if (threadIdx.x == 0) {
+      const int t = __hip_atomic_fetch_add(&prm.queue[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;   // counters start at -1
+      int item;
+      if (t < prm.n_pairs) item = t * 8;                                   // first segment of pair t: nothing to wait for
+      else {
+        const int* slot = &prm.queue[16 + (t - prm.n_pairs)];
+        long spins = 0;
+        while ((item = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
+          __builtin_amdgcn_s_sleep(32);
+          if (++spins > (1L << 24)) {                                      // ~ seconds: something is broken; give up loudly, never hang
+            __hip_atomic_store(&prm.queue[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            item = -2;
+            break;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      s_item = item;
+    }
+    __syncthreads();
+    const int item = s_item;
+    if (item < 0) return;
+    pair_id = item >> 3; seg = item & 7;
+  }
+  const PairDesc pd = pairs[pair_id];
   const int Q = pd.Q, T = pd.T, ld = pd.ld;
+  const int n_seg = prm.seg_mode ? seg_count(Q) : 1;
+  const int i_begin = seg_bound(Q, seg, n_seg), i_end = seg_bound(Q, seg + 1, n_seg);   // interior rows [i_begin, i_end)
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: the exchange loop and the boundary tests stay scalar
   const int W0 = w * GW * R;
@@ -281,9 +343,45 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
     store_row(i);
   };
 
-  // ---- row 0, row 1 -------------------------------------------------------------------------------------
-  store_row(0);   // untouched cells: score 0, null pointer (dpmatrix.cpp:17-25)
-  if (Q >= 3) {
+  // ---- hand-off slots of the segment queue: 9 x 16 bytes per thread (dk[16], gmx[16], cvk[R], lmax, lpos), chunk-major ------
+  constexpr int kStateChunks = (2 * R * X + R + 2 + 3) / 4;
+  constexpr int kStateBytes = kStateChunks * 16 * 64 * NW;
+  auto state_rsrc = [&](int sgm) {
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(prm.state) + ((size_t)pair_id * kSegs + sgm) * kStateBytes, 0,
+                                             kStateBytes, 0x00020000);
+  };
+  auto state_words = [&](uint32_t (&wv)[kStateChunks * 4], bool save) {
+    int n = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int x = 0; x < X; ++x) { if (save) wv[n] = (uint32_t)dk[r][x]; else dk[r][x] = (int)wv[n]; ++n; }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int x = 0; x < X; ++x) { if (save) wv[n] = (uint32_t)gmx[r][x]; else gmx[r][x] = (int)wv[n]; ++n; }
+#pragma unroll
+    for (int r = 0; r < R; ++r) { if (save) wv[n] = (uint32_t)cvk[r]; else cvk[r] = (int)wv[n]; ++n; }
+    if (save) { wv[n] = (uint32_t)lmax; wv[n + 1] = lpos; } else { lmax = (int)wv[n]; lpos = wv[n + 1]; }
+  };
+
+  // ---- row 0, row 1 (first segment) — or the state the previous segment left ---------------------------------------
+  if (seg > 0) {
+    const __amdgpu_buffer_rsrc_t rs = state_rsrc(seg - 1);
+    uint32_t wv[kStateChunks * 4] = {};
+#pragma unroll
+    for (int c = 0; c < kStateChunks; ++c) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (c * 64 * NW + (int)threadIdx.x) * 16, 0, 16);   // aux 16 = sc1
+      wv[4 * c] = v.x; wv[4 * c + 1] = v.y; wv[4 * c + 2] = v.z; wv[4 * c + 3] = v.w;
+    }
+    state_words(wv, false);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int x = 0; x < X; ++x) ak[r][x] = dk[r][x] + GK[r][x];
+  }
+  if (seg == 0) store_row(0);   // untouched cells: score 0, null pointer (dpmatrix.cpp:17-25)
+  if (seg == 0 && Q >= 3) {
     // row 1 (dpmatrix.h:409-418 / :579-590): match at (1,1), otherwise one deletion from the origin -> pointer (0,0)
     const int qrow = (int)qcs[1] * 128;
     auto row1 = [&](int c, int sK, int& dkv, uint32_t& pv) {
@@ -311,13 +409,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
   // of iteration i and consumed one stage later.
   const int lane_row4 = (lane & 31) * 4;
   const int hwslot = (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_ID.WAVE_ID: this wave's slot on its SIMD
-  int code_n1 = (Q >= 5) ? (int)qcs[3] : 0;                                     // residue of row i+1
-  int rowv_next = tab_at(((Q >= 4) ? (int)qcs[2] : 0) * 128, lane_row4);        // table row of row i
-  const int it_end = Q - 2 + lag * (NW - 1);
-  for (int it = 2; it <= it_end; ++it) {
+  int code_n1 = (int)qcs[min(i_begin + 1, Q - 1)];                             // residue of row i+1 (clamped: only rows <= Q-2 are consumed)
+  int rowv_next = tab_at((int)qcs[min(i_begin, Q - 1)] * 128, lane_row4);       // table row of row i
+  const int it_end = i_end - 1 + lag * (NW - 1);
+  for (int it = i_begin; it <= it_end; ++it) {
     const int i = it - lag * w;                                                  // the row this wave handles now
     const bool sync = lag == 0;
-    if (i >= 2 && i <= Q - 2) {
+    if (i >= i_begin && i < i_end) {
     int4 xin[NW > 1 ? NW - 1 : 1];
     if (NW > 1 && !sync && w > 0) {
 #pragma unroll
@@ -414,6 +512,25 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
     if (NW > 1 && !sync && (it & (lag - 1)) == lag - 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
 
+  // ---- not the pair's last segment: leave the state for whoever takes the next one, publish the item -------------------
+  if (seg + 1 < n_seg) {
+    const __amdgpu_buffer_rsrc_t rs = state_rsrc(seg);
+    uint32_t wv[kStateChunks * 4] = {};
+    state_words(wv, true);
+#pragma unroll
+    for (int c = 0; c < kStateChunks; ++c) {
+      const u32x4 v = {wv[4 * c], wv[4 * c + 1], wv[4 * c + 2], wv[4 * c + 3]};
+      __builtin_amdgcn_raw_buffer_store_b128(v, rs, (c * 64 * NW + (int)threadIdx.x) * 16, 0, 16);             // aux 16 = sc1 (write-through)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its stores (the plane rows too) ...
+    __syncthreads();                                       // ... before ONE lane publishes
+    if (threadIdx.x == 0) {
+      const int idx = __hip_atomic_fetch_add(&prm.queue[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+      __hip_atomic_store(&prm.queue[16 + idx], pair_id * 8 + seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+
   // ---- last row: untouched except the corner, which dp_corner_kernel writes --------------------------------
   if (Q >= 2) {
 #pragma unroll
@@ -440,9 +557,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
       for (int v = 0; v < NW; ++v) if (red[v][0] == gm) gp = min(gp, (uint32_t)red[v][1]);
       m = gm; p = gp;
     }
-    if (threadIdx.x == 0) { res[blockIdx.x].part_max = (float)(m >> KB); res[blockIdx.x].part_pos = p; }
+    if (threadIdx.x == 0) { res[pair_id].part_max = (float)(m >> KB); res[pair_id].part_pos = p; }
   } else {
-    if (threadIdx.x == 0) { res[blockIdx.x].part_max = 0.f; res[blockIdx.x].part_pos = 0xFFFFFFFFu; }
+    if (threadIdx.x == 0) { res[pair_id].part_max = 0.f; res[pair_id].part_pos = 0xFFFFFFFFu; }
   }
 }
 
@@ -480,6 +597,32 @@ static int launch_tag_variant(aln_batch* b, const TagParams& prm_in) {
   while (prm.lag * NW > 16) prm.lag >>= 1;                 // the ring has 16 slots: lag * (NW-1) + lag <= 16
   dim3 grid(b->n_pairs), block(64 * NW);
   hipStream_t st = b->ctx->stream;
+  // segment queue (see the kernel): hint "tag_segments" 1 = when the batch alone fills the GPU and its pairs are long, 2 = always
+  const int want = b->ctx->hints.tag_segments;
+  prm.seg_mode = 0; prm.n_pairs = b->n_pairs; prm.queue = nullptr; prm.state = nullptr;
+  if (want >= 2 || (want == 1 && b->n_pairs >= 512 && R * X == 16)) {
+    long items = 0;
+    for (const PairDesc& d : b->h_pairs) items += seg_count(d.Q);
+    if (items > b->n_pairs) {
+      constexpr size_t kStateBytes = (size_t)((2 * R * X + R + 2 + 3) / 4) * 16 * 64 * NW;
+      const size_t qbytes = ((size_t)(16 + (items - b->n_pairs)) * 4 + 15) & ~(size_t)15;
+      const size_t sbytes = (size_t)b->n_pairs * kSegs * kStateBytes;
+      if (b->tagq_bytes < qbytes) {
+        if (b->d_tagq) { ALN_HIP_CHECK(b->ctx, hipStreamSynchronize(st)); hipFree(b->d_tagq); b->d_tagq = nullptr; b->tagq_bytes = 0; }
+        ALN_HIP_CHECK(b->ctx, hipMalloc((void**)&b->d_tagq, qbytes));
+        b->tagq_bytes = qbytes;
+      }
+      if (b->tagstate_bytes < sbytes) {
+        if (b->d_tagstate) { ALN_HIP_CHECK(b->ctx, hipStreamSynchronize(st)); hipFree(b->d_tagstate); b->d_tagstate = nullptr; b->tagstate_bytes = 0; }
+        ALN_HIP_CHECK(b->ctx, hipMalloc((void**)&b->d_tagstate, sbytes));
+        b->tagstate_bytes = sbytes;
+      }
+      ALN_HIP_CHECK(b->ctx, hipMemsetAsync(b->d_tagq, 0xFF, qbytes, st));      // counters -1, error word -1, every slot "empty"
+      prm.seg_mode = 1; prm.queue = b->d_tagq; prm.state = b->d_tagstate;
+      grid = dim3((unsigned)items);
+    }
+  }
+  b->tag_segmented = prm.seg_mode != 0;
   const bool k16 = b->islocal && b->h_mode == 1 && tag_key16_legal(b) && b->ctx->hints.key16;
   if (k16)
     hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, true, true, 16, X>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
@@ -494,8 +637,8 @@ static int launch_tag_variant(aln_batch* b, const TagParams& prm_in) {
     hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, false, false, 13, X>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
                        b->d_H, b->d_P, b->d_res, prm);
   char nm[96];
-  snprintf(nm, sizeof nm, "dp_affine_tag_kernel<NW=%d,R=%d,%s%s%s%s>", NW, R, X == 8 ? "X=8," : "", b->islocal ? "local" : "global",
-           b->h_mode == 1 ? ",h16" : "", k16 ? ",key16" : "");
+  snprintf(nm, sizeof nm, "dp_affine_tag_kernel<NW=%d,R=%d,%s%s%s%s>%s", NW, R, X == 8 ? "X=8," : "", b->islocal ? "local" : "global",
+           b->h_mode == 1 ? ",h16" : "", k16 ? ",key16" : "", prm.seg_mode ? "+segq" : "");
   b->kernel_name = nm;
   ALN_HIP_CHECK(b->ctx, hipGetLastError());
   return ALN_OK;

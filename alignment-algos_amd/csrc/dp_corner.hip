@@ -19,7 +19,8 @@ __global__ __launch_bounds__(kCornerThreads) void dp_corner_kernel(const PairDes
                                                        const float* __restrict__ tgi, const float* __restrict__ tge,
                                                        float* __restrict__ Hbase, uint32_t* __restrict__ Pbase,
                                                        const float* __restrict__ Sbase, PairResult* __restrict__ res,
-                                                       int islocal, int full_build, int rev, int bug_b4, int ptr_mode, int h_mode) {
+                                                       int islocal, int full_build, int rev, int bug_b4, int ptr_mode, int h_mode,
+                                                       const int* __restrict__ dp_error) {
   const PairDesc pd = pairs[blockIdx.x];
   EvalDev e = proto;
   e.Q = pd.Q; e.T = pd.T; e.ld = pd.ld;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(kCornerThreads) void dp_corner_kernel(const PairDes
     }
     PairResult r = res[blockIdx.x];
     r.corner = corner;
-    r.status = 0;
+    r.status = (dp_error && *dp_error == 1) ? ALN_E_HIP : 0;   // the DP kernel's segment queue gave up waiting (never expected)
     if (local && full_build) {
       // find_max: the seed keeps ties, otherwise the first strictly greater cell of the scan wins.
       // forward (optimal.h:111-113): seed (Q-2,T-2); reverse (optimal_rev.h:120-122): seed (0,0) = the final cell.
@@ -139,7 +140,8 @@ int launch_dp_corner(aln_batch* b) {
   hipLaunchKernelGGL(dp_corner_kernel, dim3(b->n_pairs), dim3(kCornerThreads), 0, b->ctx->stream, b->d_pairs, proto,
                      sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr,
                      tpos ? b->d_tge : nullptr, b->d_H, b->d_P, sub ? nullptr : b->d_S, b->d_res,
-                     (int)b->islocal, (int)!b->have_sub, (int)(b->direction == ALN_REV), (int)b->bug_b4, (int)b->ptr_mode, (int)b->h_mode);
+                     (int)b->islocal, (int)!b->have_sub, (int)(b->direction == ALN_REV), (int)b->bug_b4, (int)b->ptr_mode, (int)b->h_mode,
+                     b->tag_segmented ? b->d_tagq + 2 : nullptr);
   ALN_HIP_CHECK(b->ctx, hipGetLastError());
   return ALN_OK;
 }

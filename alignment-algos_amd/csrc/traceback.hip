@@ -28,6 +28,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PairDesc* __restric
   const int ld = pd.ld, lane = threadIdx.x;
   int32_t* o = out + (size_t)blockIdx.x * prm.stride * 2;
   PairResult r = res[blockIdx.x];
+  if (r.status == ALN_E_HIP) return;            // the build of this batch failed (dp_corner.hip): nothing to trace, keep the status
   const int Q = pd.Q, T = pd.T;
   const int sg = prm.rev ? 1 : -1;              // direction the stored pointers lead in
   int n = 0, status = 0;

@@ -175,12 +175,13 @@ int aln_ctx_synchronize(aln_ctx* ctx);
  * "hipv4-amdgcn-amd-amdhsa--gfx950" is looked up in the file itself; needs no GPU), else 0. */
 int aln_has_gfx950(void);
 /* Tuning / kernel-selection hints of ONE context.  A context reads its defaults from the environment once, when it is created
- * (ALN_NO_TAG_KERNEL, ALN_NO_H16, ALN_NO_KEY16, ALN_TAG_ALT_PRIO, ALN_TAG_PERSISTENT, ALN_DP_VARIANT="NW,R[,X]", ALN_EXACT_NO_TILES,
+ * (ALN_NO_TAG_KERNEL, ALN_NO_H16, ALN_NO_KEY16, ALN_TAG_ALT_PRIO, ALN_TAG_SEGMENTS, ALN_DP_VARIANT="NW,R[,X]", ALN_EXACT_NO_TILES,
  * ALN_EXACT_LITERAL, ALN_EXACT_ALT_PRIO, ALN_SCORE_NO_PACKED, ALN_ENUM_NODE_CAP, ALN_TAG_LAG, ALN_ENUM_POOL_RETRIES); launches never read the environment.  Keys:
  *   "tag_kernel" "h16" "key16"     1/0: tagged-key kernel / uint16 score plane / 16-bit key layout allowed (results identical)
  *   "tag_alt_prio"                  1/0: row-alternating wave priority in the tagged kernel (a scheduling hint; pays when launches
  *                                   follow each other on one stream, loses when launches of several contexts overlap)
- *   "tag_persistent"                1/0: persistent workgroups pulling pairs from a queue / one workgroup per pair
+ *   "tag_segments"                  tagged kernel: 0 one workgroup per pair; 1 (default) (pair, row-segment) work items handed out by a
+ *                                   device queue when the batch alone fills the GPU; 2 whenever the pairs are long enough
  *   "dp_variant_nw" "dp_variant_r" "dp_variant_x"   force a row-sweep instantiation (0 = automatic)
  *   "exact_tiles" "exact_literal" "exact_alt_prio" "score_packed" "enum_node_cap" "tag_lag"
  *   "enum_pool_retries"             aln_batch_enumerate_all: how often a pair whose pools overflowed is searched again with four

@@ -727,3 +727,41 @@ def test_skewed_exchange_lags_agree(variant, blosum62):
                 assert np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (variant, lag, mode, p)
                 assert np.array_equal(PQ, PQ0) and np.array_equal(PT, PT0), (variant, lag, mode, p)
             b.close()
+
+
+def test_segment_queue_is_invisible(blosum62):
+    """The segment queue of the tagged kernel (context hint "tag_segments": a pair's rows are built by up to six workgroups that
+    take (pair, segment) items from a device queue and hand the row state on through HBM): ragged batch with pairs below and
+    above the 512-row threshold, local and global, 1-, 2- and 4-wave instantiations, repeated launches on the same batch (the
+    queue is reset by every launch) — planes, scores and paths equal the one-workgroup-per-pair launch, which the oracle and
+    the reference goldens pin; one mid-size pair is compared with the oracle directly."""
+    alpha, table = blosum62
+    lens = [(2000, 1990), (511, 700), (512, 640), (513, 100), (1300, 2046), (3, 3), (700, 700), (1999, 64), (640, 1500)]
+    pairs = [homolog_pair(79000 + n, max(q, t))for n, (q, t) in enumerate(lens)]
+    qs = [p[0][:q] for p, (q, t) in zip(pairs, lens)]
+    ts = [p[1][:t] for p, (q, t) in zip(pairs, lens)]
+    ctx = gpu_util.ctx()
+    S = orc.sim_submatrix(qs[6], ts[6], alpha, table)
+    for mode in (3, 1):
+        rc, D0, PQ0, PT0 = orc.dp_build(S, orc.Gap(mode, 11, 1))
+        for variant in ({}, {"dp_variant_nw": 1, "dp_variant_r": 4, "dp_variant_x": 8}, {"dp_variant_nw": 4, "dp_variant_r": 2, "dp_variant_x": 4}):
+            res = {}
+            for segq in (0, 2):
+                with ctx.hints(tag_segments=segq, **variant):
+                    b = aln_amd.Batch(ctx, qs, ts)
+                    b.dp_submatrix(alpha, table, mode, 11, 1, aln_amd.FWD, aln_amd.DP_FAST)
+                    assert b.kernel_name().endswith("+segq") == (segq == 2), b.kernel_name()
+                    for rep in range(3):
+                        b.reevaluate()
+                    sc, lists, st = b.optimal()
+                    res[segq] = ([b.get_cells(p) for p in range(len(qs))], sc, lists, st)
+                    b.close()
+            a, c = res[0], res[2]
+            assert (a[3] == 0).all() and (c[3] == 0).all()
+            assert np.array_equal(a[1].view(np.uint32), c[1].view(np.uint32))
+            for p in range(len(qs)):
+                for x, y in zip(a[0][p], c[0][p]):
+                    assert np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32)), (mode, variant, p)
+                assert np.array_equal(a[2][p], c[2][p])
+            D, PQ, PT = c[0][6]
+            assert np.array_equal(D.view(np.uint32), D0.view(np.uint32)) and np.array_equal(PQ, PQ0) and np.array_equal(PT, PT0)
