@@ -116,11 +116,13 @@ __device__ __forceinline__ uint32_t pack_ptr(int pq, int pt) { return ((uint32_t
 
 // Pointer words of the P plane.  mode 0 (dp_affine_int, dp_exact): prev_q << 16 | prev_t.  mode 1 (dp_affine_tag):
 // the low 13 bits of the winning key: prio << 11 | tag, prio 3 = match -> (i-1,j-1), 2 = deletion -> (i-1, 2047-tag),
-// 1 = insertion -> (2047-tag, j-1).  0xFFFFFFFF = untouched cell (DPCell::null, null) in both.
+// 1 = insertion -> (2047-tag, j-1).  mode 2: the same with 12 tag bits (prio << 12 | tag, 4095 - tag; sequences up to 4096).
+// 0xFFFFFFFF = untouched cell (DPCell::null, null) in all.
 __host__ __device__ __forceinline__ void decode_ptr(uint32_t w, int mode, int i, int j, int& pq, int& pt) {
   if (w == 0xFFFFFFFFu) { pq = -1; pt = -1; return; }
   if (mode == 0) { pq = (int)(w >> 16); pt = (int)(w & 0xFFFFu); if (pq == 0xFFFF) pq = -1; if (pt == 0xFFFF) pt = -1; return; }
-  const int prio = (int)((w >> 11) & 3u), k = 2047 - (int)(w & 2047u);
+  const int tb = mode == 2 ? 12 : 11, tmax = (1 << tb) - 1;          // dialect 2: 12 tag bits (sequences up to 4096)
+  const int prio = (int)((w >> tb) & 3u), k = tmax - (int)(w & (uint32_t)tmax);
   if (prio == 3) { pq = i - 1; pt = j - 1; }
   else if (prio == 2) { pq = i - 1; pt = k; }
   else { pq = k; pt = j - 1; }
@@ -152,9 +154,10 @@ __host__ __device__ __forceinline__ void store_score(float* Hbase, int64_t plane
 }
 __host__ __device__ __forceinline__ uint32_t encode_ptr(int mode, int i, int j, int pq, int pt) {
   if (mode == 0) return ((uint32_t)pq << 16) | ((uint32_t)pt & 0xFFFFu);
-  if (pq == i - 1 && pt == j - 1) return 3u << 11;
-  if (pq == i - 1) return (2u << 11) | (uint32_t)(2047 - pt);
-  return (1u << 11) | (uint32_t)(2047 - pq);
+  const int tb = mode == 2 ? 12 : 11, tmax = (1 << tb) - 1;
+  if (pq == i - 1 && pt == j - 1) return 3u << tb;
+  if (pq == i - 1) return (2u << tb) | (uint32_t)(tmax - pt);
+  return (1u << tb) | (uint32_t)(tmax - pq);
 }
 
 }  // namespace aln

@@ -64,8 +64,9 @@ struct aln_hints {
                              // synchronous per-row exchange.  Measured on MI355X (config 2, lone launches): lag 0 3.11 ms, 1: 3.20, 2: 3.10,
                              // 4: 3.28; four overlapping streams 2.82 vs 3.38 — the waves of a pair drifting apart costs more in HBM
                              // row locality (the two halves of a plane row are written rows apart) than the barrier chain it removes
-  int tag_segments = 1;      // tagged kernel: (pair, row segment) work items handed out by a queue (dp_affine_tag.hip "Segment queue"):
-                             // 0 = one workgroup per pair, 1 = when the batch alone fills the GPU (>= 512 long pairs), 2 = whenever pairs are long
+  int tag_segments = 0;      // tagged kernel: (pair, row segment) work items handed out by a queue (dp_affine_tag.hip "Segment queue"):
+                             // K in 2..8 = long pairs are cut into K segments when the batch alone fills the GPU (>= 512 pairs), -K = whenever
+                             // pairs are long, 0 = one workgroup per pair
   int dp_nw = 0, dp_r = 0, dp_x = 0;   // force a row-sweep variant (waves per pair, groups per lane, columns per lane and group); 0 = auto
   int exact_tiles = 1;       // 0: dp_exact_blocked instead of dp_exact_tiled where both apply
   int exact_literal = 0;     // 1: the literal O(n^3) kernel everywhere
@@ -159,6 +160,8 @@ bool fast_path_legal(const aln_batch* b, const float* table, int n, const aln_ga
 // dp_affine_tag.hip
 int launch_dp_affine_tag(aln_batch* b);
 bool tag_path_legal(const aln_batch* b, const float* table, int n, const aln_gap* gap);
+int tag_path_bits(const aln_batch* b, const float* table, int n, const aln_gap* gap);   // 0 (not legal), 11 or 12 tag bits
+bool tag_h16_legal(const aln_batch* b);
 // dp_corner.hip
 int launch_dp_corner(aln_batch* b);
 // traceback.hip

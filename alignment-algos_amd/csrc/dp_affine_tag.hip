@@ -30,14 +30,19 @@
 
 namespace aln {
 
-namespace tag {
-constexpr int TAGMAX = 2047;
-constexpr int P_MATCH = 3 << 11, P_DEL = 2 << 11, P_INS = 1 << 11;
-constexpr int NEGK = -(1 << 30);            // value -2^17: below every real value (|v| < 2^16), headroom for one subtraction
-constexpr int ZKEY = P_MATCH;               // (value 0, match): the clip of local alignments
-constexpr int ORIGIN_DEL = P_DEL | TAGMAX;  // pointer (i-1, 0): cells of row 1 come from the origin by one deletion
-constexpr int ORIGIN_INS = P_INS | TAGMAX;  // pointer (0, j-1): cells of column 1
-}  // namespace tag
+// Key layout for TB tag bits (TB = 11: sequences up to 2048, TB = 12: up to 4096; pointer-word dialects 1 and 2 of
+// aln_device.h::decode_ptr):  key = value << (TB+2) | prio << TB | tag,  tag = (2^TB - 1) - k.
+template <int TB>
+struct TagBits {
+  static constexpr int TAGMAX = (1 << TB) - 1;
+  static constexpr int P_MATCH = 3 << TB, P_DEL = 2 << TB, P_INS = 1 << TB;
+  // "minus infinity": below every real value, with headroom for one subtraction of a gap constant.
+  // TB 11 (value << 13): -2^17, real values stay inside +-2^16.  TB 12 (value << 14, range +-2^17): -114688, real values inside +-100000.
+  static constexpr int NEGK = (TB == 11) ? -(1 << 30) : -(7 << 28);
+  static constexpr int ZKEY = P_MATCH;               // (value 0, match): the clip of local alignments
+  static constexpr int ORIGIN_DEL = P_DEL | TAGMAX;  // pointer (i-1, 0): cells of row 1 come from the origin by one deletion
+  static constexpr int ORIGIN_INS = P_INS | TAGMAX;  // pointer (0, j-1): cells of column 1
+};
 
 struct TagParams {
   int gi, ge;
@@ -47,10 +52,11 @@ struct TagParams {
                   // L = 2^k >= 1: wave w runs L*w rows behind wave 0 and reads what the earlier waves left in a ring of
                   // exchange slots, one workgroup barrier every L rows (see "skewed exchange" below)
   // ---- segment queue (see "Segment queue" in the kernel) ----
-  int seg_mode;   // 0: workgroup b builds pair b from its first to its last row; 1: workgroups take (pair, row segment) items
   int n_pairs;
-  int* queue;     // [0] ticket counter, [1] push counter, [2] error word, [16 ...] item slots; every word 0xFFFFFFFF before the launch
-  uint32_t* state;   // hand-off slots: (pair * kSegs + segment) * kStateBytes
+  int ksegs;      // segments a long pair is cut into (2 .. 8)
+  int* queue;     // SEGQ kernels: [0] ticket counter, [1] push counter, [2] error word — all 0xFFFFFFFF before a launch;
+                  // [4..5] address of the hand-off slots ((pair * kSegs + segment) * kStateBytes), written once;
+                  // [16 ...] item slots, 0xFFFFFFFF before a launch
 };
 
 // Segment queue.  With one workgroup per pair a batch of 1024 pairs x 2 waves fills the 1024 SIMDs exactly once: the SIMD arbiter
@@ -68,15 +74,16 @@ struct TagParams {
 // publishes the item with an agent-scope atomic store; the consumer polls that one word (relaxed, agent scope), executes one
 // agent-scope acquire, and the workgroup reads the state with sc1 loads behind a barrier.  Every hand-off slot is written once
 // and read once per launch (slot = pair x segment), so no line is rewritten while a stale copy could sit in another XCD's L2.
-constexpr int kSegs = 6;
+constexpr int kSegs = 8;                               // most segments a pair can have (item = pair * 8 + segment)
 constexpr int kSegMinRows = 512;                       // pairs with fewer rows are one segment
-__host__ __device__ inline int seg_count(int Q) { return Q >= kSegMinRows ? kSegs : 1; }
-// first interior row of segment s (s = 0 .. n): interior rows are 2 .. Q-2; weights 6:5:4:3:2:1
+__host__ __device__ inline int seg_count(int Q, int ksegs) { return Q >= kSegMinRows ? ksegs : 1; }
+// first interior row of segment s (s = 0 .. n): interior rows are 2 .. Q-2; segment lengths in the ratio n : n-1 : ... : 1
 __host__ __device__ inline int seg_bound(int Q, int s, int n) {
   if (n == 1) return s == 0 ? 2 : Q - 1;
-  const int cum[kSegs + 1] = {0, 6, 11, 15, 18, 20, 21};
+  if (s >= n) return Q - 1;
   const int rows = Q - 3 > 0 ? Q - 3 : 0;
-  return s >= n ? Q - 1 : 2 + (int)(((long)rows * cum[s]) / 21);
+  const long cum = (long)s * n - (long)s * (s - 1) / 2, total = (long)n * (n + 1) / 2;
+  return 2 + (int)((rows * cum) / total);
 }
 
 template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
@@ -119,20 +126,24 @@ __device__ __forceinline__ void wave_incl_max_keys(int (&v)[R]) {
 // is exactly 2 waves per SIMD, but the dispatcher does not spread them evenly on its own (3 on some SIMDs, 1 on others: measured
 // +20 % kernel time, and it varies with unrelated code changes).  amdgpu_waves_per_eu(2,2) makes the compiler allocate for
 // exactly two waves per SIMD (it rounds the VGPR allocation up so that a third cannot be placed), which caps every SIMD at 2.
-template <int NW, int R, bool LOCAL, bool H16, int KBT, int X>
+// SEGQ: workgroups take (pair, row segment) items from the queue instead of building pair blockIdx.x from first to last row.
+template <int NW, int R, bool LOCAL, bool H16, int KBT, int X, bool SEGQ, int TB>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X == 16 ? 2 : 1, R * X == 16 ? 2 : 8))) void dp_affine_tag_kernel(
     const PairDesc* __restrict__ pairs, const uint8_t* __restrict__ qcodes, const uint8_t* __restrict__ tcodes,
     const int32_t* __restrict__ table32, float* __restrict__ Hbase, uint32_t* __restrict__ Pbase,
     PairResult* __restrict__ res, TagParams prm) {
-  using namespace tag;
-  constexpr int KB = KBT;
+  typedef TagBits<TB> tag;
+  constexpr int TAGMAX = tag::TAGMAX, P_MATCH = tag::P_MATCH, P_DEL = tag::P_DEL, P_INS = tag::P_INS;
+  constexpr int ZKEY = tag::ZKEY, ORIGIN_DEL = tag::ORIGIN_DEL, ORIGIN_INS = tag::ORIGIN_INS;
+  constexpr int KB = (KBT == 16) ? 16 : TB + 2;                // KBT: 13 = "value right above the tag bits", 16 = score in the high half
   constexpr int LOW = (1 << KB) - 1;
   constexpr int NEGK = (KBT == 16) ? -(1 << 29) : tag::NEGK;   // value -8192 at KB = 16
   static_assert(KBT == 13 || (KBT == 16 && LOCAL && H16), "the 16-bit key layout needs non-negative 15-bit scores");
+  static_assert(TB == 11 || TB == 12, "11 or 12 tag bits");
   static_assert(X == 4 || X == 8, "a lane owns 4 or 8 consecutive columns of each group");
   constexpr int GW = 64 * X;            // columns of one group (one lane-contiguous stretch of a row)
   __shared__ int tab[32 * 32];          // substitution scores << KB
-  __shared__ uint8_t qcs[2048];         // the query's residue codes (Q <= 2048): one LDS byte per row instead of a global load
+  __shared__ uint8_t qcs[1 << TB];      // the query's residue codes (Q <= 2^TB): one LDS byte per row instead of a global load
   constexpr int RING = 16;              // exchange slots: one per row, reused every 16 rows
   __shared__ __attribute__((aligned(16))) int xch[RING][NW][4];
   __shared__ int red[NW][2];
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
   // ---- which pair, which rows ------------------------------------------------------------------------------------
   __shared__ int s_item;
   int pair_id = blockIdx.x, seg = 0;
-  if (prm.seg_mode) {
+  if constexpr (SEGQ) {
     if (threadIdx.x == 0) {
       const int t = __hip_atomic_fetch_add(&prm.queue[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;   // counters start at -1
       int item;
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
   }
   const PairDesc pd = pairs[pair_id];
   const int Q = pd.Q, T = pd.T, ld = pd.ld;
-  const int n_seg = prm.seg_mode ? seg_count(Q) : 1;
+  const int n_seg = SEGQ ? seg_count(Q, prm.ksegs) : 1;
   const int i_begin = seg_bound(Q, seg, n_seg), i_end = seg_bound(Q, seg + 1, n_seg);   // interior rows [i_begin, i_end)
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: the exchange loop and the boundary tests stay scalar
@@ -346,9 +357,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
   // ---- hand-off slots of the segment queue: 9 x 16 bytes per thread (dk[16], gmx[16], cvk[R], lmax, lpos), chunk-major ------
   constexpr int kStateChunks = (2 * R * X + R + 2 + 3) / 4;
   constexpr int kStateBytes = kStateChunks * 16 * 64 * NW;
-  auto state_rsrc = [&](int sgm) {
-    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(prm.state) + ((size_t)pair_id * kSegs + sgm) * kStateBytes, 0,
-                                             kStateBytes, 0x00020000);
+  // (the slots' address is read from the queue header where it is needed, the item is re-read from LDS at the end: nothing of the
+  // queue stays in registers across the row loop except the queue pointer)
+  auto state_rsrc = [&](int pr, int sgm) {
+    char* base = *reinterpret_cast<char* volatile*>(&prm.queue[4]);
+    return __builtin_amdgcn_make_buffer_rsrc(base + ((size_t)pr * kSegs + sgm) * kStateBytes, 0, kStateBytes, 0x00020000);
   };
   auto state_words = [&](uint32_t (&wv)[kStateChunks * 4], bool save) {
     int n = 0;
@@ -366,8 +379,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
   };
 
   // ---- row 0, row 1 (first segment) — or the state the previous segment left ---------------------------------------
-  if (seg > 0) {
-    const __amdgpu_buffer_rsrc_t rs = state_rsrc(seg - 1);
+  if (SEGQ && seg > 0) {
+    const __amdgpu_buffer_rsrc_t rs = state_rsrc(pair_id, seg - 1);
     uint32_t wv[kStateChunks * 4] = {};
 #pragma unroll
     for (int c = 0; c < kStateChunks; ++c) {
@@ -513,8 +526,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
   }
 
   // ---- not the pair's last segment: leave the state for whoever takes the next one, publish the item -------------------
-  if (seg + 1 < n_seg) {
-    const __amdgpu_buffer_rsrc_t rs = state_rsrc(seg);
+  int pair_out = pair_id;
+  if constexpr (SEGQ) {
+    const int item = *reinterpret_cast<volatile int*>(&s_item);
+    pair_out = item >> 3;
+    const int seg_out = item & 7;
+    if (seg_out + 1 < seg_count(Q, prm.ksegs)) {
+    const __amdgpu_buffer_rsrc_t rs = state_rsrc(pair_out, seg_out);
     uint32_t wv[kStateChunks * 4] = {};
     state_words(wv, true);
 #pragma unroll
@@ -526,9 +544,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
     __syncthreads();                                       // ... before ONE lane publishes
     if (threadIdx.x == 0) {
       const int idx = __hip_atomic_fetch_add(&prm.queue[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-      __hip_atomic_store(&prm.queue[16 + idx], pair_id * 8 + seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&prm.queue[16 + idx], item + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return;
+    }
   }
 
   // ---- last row: untouched except the corner, which dp_corner_kernel writes --------------------------------
@@ -557,28 +576,41 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
       for (int v = 0; v < NW; ++v) if (red[v][0] == gm) gp = min(gp, (uint32_t)red[v][1]);
       m = gm; p = gp;
     }
-    if (threadIdx.x == 0) { res[pair_id].part_max = (float)(m >> KB); res[pair_id].part_pos = p; }
+    if (threadIdx.x == 0) { res[pair_out].part_max = (float)(m >> KB); res[pair_out].part_pos = p; }
   } else {
-    if (threadIdx.x == 0) { res[pair_id].part_max = 0.f; res[pair_id].part_pos = 0xFFFFFFFFu; }
+    if (threadIdx.x == 0) { res[pair_out].part_max = 0.f; res[pair_out].part_pos = 0xFFFFFFFFu; }
   }
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
 
-// Tagged keys need |every intermediate value| < 2^16 and 11-bit indices.
-bool tag_path_legal(const aln_batch* b, const float* table, int n, const aln_gap* gap) {
-  if (!table || gap->model != ALN_GAP_AFFINE_CONST) return false;
-  if (b->maxQ > 2048 || b->maxT > 2048) return false;
+// Tagged keys: integer values, and every intermediate inside the key's value field.
+//   sequences up to 2048 (11 tag bits, 19 value bits): the crude bound (max|S| + ge)(Q + T) + gi + max|S| < 2^16;
+//   up to 4096 (12 tag bits, 18 value bits, "minus infinity" at -114688): |D| <= max|S| min(Q,T) + gi + ge max(Q,T) (a score is a
+//   sum of at most min(Q,T) similarities minus gaps, and at least the score of the path "diagonal, then one gap"); source keys
+//   add ge * column or ge * row, candidates subtract gi + ge * length once more -> max|S| min + 2 gi + 3 ge max + max|S| < 100000,
+//   and gi + ge * length < 16000 so that "minus infinity" minus a gap constant stays inside the field.
+int tag_path_bits(const aln_batch* b, const float* table, int n, const aln_gap* gap) {
+  if (!table || gap->model != ALN_GAP_AFFINE_CONST) return 0;
+  if (b->maxQ > 4096 || b->maxT > 4096) return 0;
   const float gi = gap->gap_init, ge = gap->gap_extn;
-  if (!(gi == (float)(int)gi) || !(ge == (float)(int)ge) || gi < 0 || ge < 0) return false;
+  if (!(gi == (float)(int)gi) || !(ge == (float)(int)ge) || gi < 0 || ge < 0) return 0;
   double maxs = 0;
   for (int k = 0; k < n * n; ++k) {
     const float v = table[k];
-    if (!(v == (float)(int)v)) return false;
+    if (!(v == (float)(int)v)) return 0;
     if (fabs((double)v) > maxs) maxs = fabs((double)v);
   }
-  const double bound = (maxs + ge) * ((double)b->maxQ + (double)b->maxT) + gi + maxs;
-  return bound < 65536.0;
+  const double mn = (double)std::min(b->maxQ, b->maxT), mx = (double)std::max(b->maxQ, b->maxT);
+  if (b->maxQ <= 2048 && b->maxT <= 2048) return (maxs + ge) * ((double)b->maxQ + (double)b->maxT) + gi + maxs < 65536.0 ? 11 : 0;
+  return (maxs * mn + 2 * gi + 3 * ge * mx + maxs < 100000.0 && gi + ge * mx < 16000.0) ? 12 : 0;
+}
+bool tag_path_legal(const aln_batch* b, const float* table, int n, const aln_gap* gap) { return tag_path_bits(b, table, n, gap) != 0; }
+// uint16 score planes of local tagged builds: every score is in [0, max|S| min(Q,T)]
+bool tag_h16_legal(const aln_batch* b) {
+  double maxs = 0;
+  for (float v : b->h_table) maxs = std::max(maxs, fabs((double)v));
+  return maxs * (double)std::min(b->maxQ, b->maxT) < 65536.0;
 }
 
 // The 16-bit key layout (score = high half of the key): local builds only (scores >= 0), best score + the A-space offset
@@ -591,54 +623,55 @@ static bool tag_key16_legal(const aln_batch* b) {
   return best + ge * L + maxs < 32767.0 && gi + ge * L + maxs < 8000.0;
 }
 
-template <int NW, int R, int X>
+template <int NW, int R, int X, int TB>
 static int launch_tag_variant(aln_batch* b, const TagParams& prm_in) {
   TagParams prm = prm_in;
   while (prm.lag * NW > 16) prm.lag >>= 1;                 // the ring has 16 slots: lag * (NW-1) + lag <= 16
   dim3 grid(b->n_pairs), block(64 * NW);
   hipStream_t st = b->ctx->stream;
-  // segment queue (see the kernel): hint "tag_segments" 1 = when the batch alone fills the GPU and its pairs are long, 2 = always
+  // segment queue (see the kernel): hint "tag_segments" = K: long pairs are cut into K segments (2 .. 8) when the batch alone fills
+  // the GPU (>= 512 pairs); -K: whenever pairs are long; 0 / 1: off
   const int want = b->ctx->hints.tag_segments;
-  prm.seg_mode = 0; prm.n_pairs = b->n_pairs; prm.queue = nullptr; prm.state = nullptr;
-  if (want >= 2 || (want == 1 && b->n_pairs >= 512 && R * X == 16)) {
+  prm.n_pairs = b->n_pairs; prm.queue = nullptr;
+  prm.ksegs = std::min(std::abs(want), kSegs);
+  bool segq = false;
+  if (prm.ksegs >= 2 && (want < 0 || (b->n_pairs >= 512 && R * X == 16))) {
     long items = 0;
-    for (const PairDesc& d : b->h_pairs) items += seg_count(d.Q);
+    for (const PairDesc& d : b->h_pairs) items += seg_count(d.Q, prm.ksegs);
     if (items > b->n_pairs) {
       constexpr size_t kStateBytes = (size_t)((2 * R * X + R + 2 + 3) / 4) * 16 * 64 * NW;
       const size_t qbytes = ((size_t)(16 + (items - b->n_pairs)) * 4 + 15) & ~(size_t)15;
       const size_t sbytes = (size_t)b->n_pairs * kSegs * kStateBytes;
-      if (b->tagq_bytes < qbytes) {
-        if (b->d_tagq) { ALN_HIP_CHECK(b->ctx, hipStreamSynchronize(st)); hipFree(b->d_tagq); b->d_tagq = nullptr; b->tagq_bytes = 0; }
+      if (b->tagq_bytes < qbytes || b->tagstate_bytes < sbytes) {
+        ALN_HIP_CHECK(b->ctx, hipStreamSynchronize(st));
+        hipFree(b->d_tagq); hipFree(b->d_tagstate); b->d_tagq = nullptr; b->d_tagstate = nullptr; b->tagq_bytes = b->tagstate_bytes = 0;
         ALN_HIP_CHECK(b->ctx, hipMalloc((void**)&b->d_tagq, qbytes));
-        b->tagq_bytes = qbytes;
-      }
-      if (b->tagstate_bytes < sbytes) {
-        if (b->d_tagstate) { ALN_HIP_CHECK(b->ctx, hipStreamSynchronize(st)); hipFree(b->d_tagstate); b->d_tagstate = nullptr; b->tagstate_bytes = 0; }
         ALN_HIP_CHECK(b->ctx, hipMalloc((void**)&b->d_tagstate, sbytes));
-        b->tagstate_bytes = sbytes;
+        b->tagq_bytes = qbytes; b->tagstate_bytes = sbytes;
+        ALN_HIP_CHECK(b->ctx, hipMemcpy(b->d_tagq + 4, &b->d_tagstate, 8, hipMemcpyHostToDevice));   // header words 4..5, once
       }
-      ALN_HIP_CHECK(b->ctx, hipMemsetAsync(b->d_tagq, 0xFF, qbytes, st));      // counters -1, error word -1, every slot "empty"
-      prm.seg_mode = 1; prm.queue = b->d_tagq; prm.state = b->d_tagstate;
+      ALN_HIP_CHECK(b->ctx, hipMemsetAsync(b->d_tagq, 0xFF, 16, st));                                 // counters -1, error word -1
+      ALN_HIP_CHECK(b->ctx, hipMemsetAsync(b->d_tagq + 16, 0xFF, qbytes - 64, st));                  // every slot "empty"
+      prm.queue = b->d_tagq;
       grid = dim3((unsigned)items);
+      segq = true;
     }
   }
-  b->tag_segmented = prm.seg_mode != 0;
+  b->tag_segmented = segq;
   const bool k16 = b->islocal && b->h_mode == 1 && tag_key16_legal(b) && b->ctx->hints.key16;
-  if (k16)
-    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, true, true, 16, X>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
-                       b->d_H, b->d_P, b->d_res, prm);
-  else if (b->islocal && b->h_mode == 1)
-    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, true, true, 13, X>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
-                       b->d_H, b->d_P, b->d_res, prm);
-  else if (b->islocal)
-    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, true, false, 13, X>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
-                       b->d_H, b->d_P, b->d_res, prm);
-  else
-    hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, false, false, 13, X>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, b->d_table32,
-                       b->d_H, b->d_P, b->d_res, prm);
+#define ALN_TAG_LAUNCH(LOC_, H16_, KB_, SQ_)                                                                                         \
+  hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, LOC_, H16_, KB_, X, SQ_, TB>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, \
+                     b->d_table32, b->d_H, b->d_P, b->d_res, prm)
+#define ALN_TAG_LAUNCH_Q(LOC_, H16_, KB_) do { if (segq) ALN_TAG_LAUNCH(LOC_, H16_, KB_, true); else ALN_TAG_LAUNCH(LOC_, H16_, KB_, false); } while (0)
+  if (k16) ALN_TAG_LAUNCH_Q(true, true, 16);
+  else if (b->islocal && b->h_mode == 1) ALN_TAG_LAUNCH_Q(true, true, 13);
+  else if (b->islocal) ALN_TAG_LAUNCH_Q(true, false, 13);
+  else ALN_TAG_LAUNCH_Q(false, false, 13);
+#undef ALN_TAG_LAUNCH_Q
+#undef ALN_TAG_LAUNCH
   char nm[96];
-  snprintf(nm, sizeof nm, "dp_affine_tag_kernel<NW=%d,R=%d,%s%s%s%s>%s", NW, R, X == 8 ? "X=8," : "", b->islocal ? "local" : "global",
-           b->h_mode == 1 ? ",h16" : "", k16 ? ",key16" : "", prm.seg_mode ? "+segq" : "");
+  snprintf(nm, sizeof nm, "dp_affine_tag_kernel<NW=%d,R=%d,%s%s%s%s%s>%s", NW, R, X == 8 ? "X=8," : "", b->islocal ? "local" : "global",
+           b->h_mode == 1 ? ",h16" : "", k16 ? ",key16" : "", TB == 12 ? ",tag12" : "", segq ? "+segq" : "");
   b->kernel_name = nm;
   ALN_HIP_CHECK(b->ctx, hipGetLastError());
   return ALN_OK;
@@ -658,6 +691,8 @@ int launch_dp_affine_tag(aln_batch* b) {
   const int ld = row_stride(b->maxT);
   // variant = waves per pair, groups per lane, consecutive columns a lane owns in a group (ALN_DP_VARIANT="NW,R[,X]")
   int nw = b->ctx->hints.dp_nw, r = b->ctx->hints.dp_r, x = b->ctx->hints.dp_x ? b->ctx->hints.dp_x : 4;
+  // sequences beyond 2048 need 12 tag bits (pointer dialect 2): one instantiation, 4 waves x 2 groups x 8 columns = 4096 columns
+  if (b->ptr_mode == 2) return launch_tag_variant<4, 2, 8, 12>(b, prm);
   if (nw == 0) {
     if (ld <= 256) { nw = 1; r = 1; }
     else if (ld <= 512) { nw = 2; r = 1; }
@@ -665,7 +700,7 @@ int launch_dp_affine_tag(aln_batch* b) {
     else { nw = 2; r = 2; x = 8; }   // 2 waves x 2 groups x 8 columns per lane: half the row scans of (2,4,4)
   }
   if (64 * x * nw * r < ld) return ALN_E_TOO_LONG;
-#define ALN_V(NW_, R_, X_) if (nw == NW_ && r == R_ && x == X_) return launch_tag_variant<NW_, R_, X_>(b, prm)
+#define ALN_V(NW_, R_, X_) if (nw == NW_ && r == R_ && x == X_) return launch_tag_variant<NW_, R_, X_, 11>(b, prm)
   ALN_V(1, 1, 4); ALN_V(1, 2, 4); ALN_V(1, 4, 4); ALN_V(1, 8, 4);
   ALN_V(2, 1, 4); ALN_V(2, 2, 4); ALN_V(2, 4, 4);
   ALN_V(4, 1, 4); ALN_V(4, 2, 4);

@@ -180,8 +180,8 @@ int aln_has_gfx950(void);
  *   "tag_kernel" "h16" "key16"     1/0: tagged-key kernel / uint16 score plane / 16-bit key layout allowed (results identical)
  *   "tag_alt_prio"                  1/0: row-alternating wave priority in the tagged kernel (a scheduling hint; pays when launches
  *                                   follow each other on one stream, loses when launches of several contexts overlap)
- *   "tag_segments"                  tagged kernel: 0 one workgroup per pair; 1 (default) (pair, row-segment) work items handed out by a
- *                                   device queue when the batch alone fills the GPU; 2 whenever the pairs are long enough
+ *   "tag_segments"                  tagged kernel: 0 (default) one workgroup per pair; K in 2..8: long pairs are cut into K row
+ *                                   segments handed out by a device queue when the batch alone fills the GPU; -K: whenever pairs are long
  *   "dp_variant_nw" "dp_variant_r" "dp_variant_x"   force a row-sweep instantiation (0 = automatic)
  *   "exact_tiles" "exact_literal" "exact_alt_prio" "score_packed" "enum_node_cap" "tag_lag"
  *   "enum_pool_retries"             aln_batch_enumerate_all: how often a pair whose pools overflowed is searched again with four

@@ -8,11 +8,12 @@
         make_subopt_regions(T, 10) flags (config 4) for every DELTA_RATIO in C4_DELTAS the reference finishes.
   c3    one 2000 x 2000 GLOBAL profile pair (bench_c3's generator, seeds 3000 / 4000) through oracle/_ref/ref_profile
         (real hmath.h / SimilarityMatrix / DPMatrix / Optimal): sha256 of S, H, PQ, PT + Optimal.
+  long  four pairs between 2049 and 4094 residues (the kernels' paths beyond 2048 columns / rows): plane sha256 + Optimal.
   c5    a 32 x 32 block of config 5's sequence set (seed 5000+s, 400..600 aa): the score Optimal reports, local 11/1;
         and 12 x 12 blocks for the other four align_t.
 
 The O(n^3) reference needs ~25-40 s per 2000 x 2000 pair and core; everything runs once, in parallel, here.
-usage: gen_golden_full.py [c2] [c3] [c5]   (default: all; parts not regenerated are kept from the existing file)
+usage: gen_golden_full.py [c2] [c3] [c5] [long]   (default: all; parts not regenerated are kept from the existing file)
 """
 import hashlib
 import json
@@ -189,22 +190,55 @@ def gen_c5(pool):
             "scores": blocks}
 
 
+def run_long(args):
+    """One pair beyond 2048 residues (the tagged kernel's 12-bit tag layout, the int kernel, the exact kernel)."""
+    name, seed, qlen, tlen, homolog = args
+    if homolog:
+        q, t = homolog_pair(seed, max(qlen, tlen))
+        q, t = q[:qlen], t[:tlen]
+    else:
+        q, t = random_pair(seed, qlen, tlen)
+    os.makedirs(TMP, exist_ok=True)
+    path = os.path.join(TMP, "long_%s.bin" % name)
+    r = refrun.run_aa(q, t, 3, 11, 1, "fwd", ops=["bin", path, "opt"], timeout=7200)
+    raw = np.fromfile(path, dtype=np.int32)
+    os.remove(path)
+    Q, T = int(raw[0]), int(raw[1])
+    planes = raw[2:].reshape(3, Q, T)
+    opt = r["sets"]["OPT"]["alis"][0]
+    print("long %s: %d x %d, opt score %g (%d pairs)" % (name, qlen, tlen, float(opt["score"]), len(opt["pairs"])), flush=True)
+    return {"name": name, "seed": seed, "qlen": qlen, "tlen": tlen, "homolog": bool(homolog), "mode": 3, "gi": 11, "ge": 1,
+            "q_sha": hashlib.sha256(q.encode()).hexdigest(), "t_sha": hashlib.sha256(t.encode()).hexdigest(),
+            "sha": {"H": sha(planes[0].view(np.uint32)), "PQ": sha(planes[1]), "PT": sha(planes[2])},
+            "row_crc": {"H": row_crc(planes[0]), "P": row_crc(np.stack([planes[1], planes[2]], axis=2))},
+            "corner": int(planes[0].view(np.uint32)[-1, -1]),
+            "opt": {"score": bits(opt["score"]), "pairs": opt["pairs"].reshape(-1).tolist()}}
+
+
+LONG_CASES = [("t2049", 2100, 1500, 2049, True), ("q2049", 2101, 2049, 700, True), ("sq3000", 2102, 3000, 3000, True),
+              ("max4094", 2103, 4094, 4094, True)]
+
+
 def main():
     if not refrun.available():
         raise SystemExit("oracle/_ref/ref_harness missing: run `make -C oracle` where /root/reference exists")
-    parts = [a for a in sys.argv[1:] if a in ("c2", "c3", "c5")] or ["c2", "c3", "c5"]
+    parts = [a for a in sys.argv[1:] if a in ("c2", "c3", "c5", "long")] or ["c2", "c3", "c5", "long"]
     doc = {"generator": "oracle/gen_golden_full.py via oracle/_ref (real reference, g++ -O2, no -ffast-math)"}
     if os.path.exists(OUT):
         with open(OUT) as f:
             doc.update(json.load(f))
     with ThreadPoolExecutor(8) as pool:
         fut3 = pool.submit(gen_c3) if "c3" in parts else None
+        futl = [pool.submit(run_long, c) for c in LONG_CASES] if "long" in parts else []
         if "c5" in parts:
             doc["c5"] = gen_c5(pool)
         if "c2" in parts:
             doc["c2"] = gen_c2(pool)
         if fut3:
             doc["c3"] = fut3.result()
+        if futl:
+            doc["long"] = {"note": "pairs beyond the 2048-residue limit of the 11-bit tag layout, local 11/1 BLOSUM62; homologs truncated to "
+                                   "(qlen, tlen)", "pairs": [f.result() for f in futl]}
     with open(OUT, "w") as f:
         json.dump(doc, f, separators=(",", ":"))
     print("wrote", OUT, os.path.getsize(OUT), "bytes")

@@ -746,22 +746,24 @@ def test_segment_queue_is_invisible(blosum62):
         rc, D0, PQ0, PT0 = orc.dp_build(S, orc.Gap(mode, 11, 1))
         for variant in ({}, {"dp_variant_nw": 1, "dp_variant_r": 4, "dp_variant_x": 8}, {"dp_variant_nw": 4, "dp_variant_r": 2, "dp_variant_x": 4}):
             res = {}
-            for segq in (0, 2):
+            for segq in (0, -6, -3):
                 with ctx.hints(tag_segments=segq, **variant):
                     b = aln_amd.Batch(ctx, qs, ts)
                     b.dp_submatrix(alpha, table, mode, 11, 1, aln_amd.FWD, aln_amd.DP_FAST)
-                    assert b.kernel_name().endswith("+segq") == (segq == 2), b.kernel_name()
+                    assert b.kernel_name().endswith("+segq") == (segq != 0), b.kernel_name()
                     for rep in range(3):
                         b.reevaluate()
                     sc, lists, st = b.optimal()
                     res[segq] = ([b.get_cells(p) for p in range(len(qs))], sc, lists, st)
                     b.close()
-            a, c = res[0], res[2]
-            assert (a[3] == 0).all() and (c[3] == 0).all()
-            assert np.array_equal(a[1].view(np.uint32), c[1].view(np.uint32))
-            for p in range(len(qs)):
-                for x, y in zip(a[0][p], c[0][p]):
-                    assert np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32)), (mode, variant, p)
-                assert np.array_equal(a[2][p], c[2][p])
+            a = res[0]
+            for ks in (-6, -3):
+                c = res[ks]
+                assert (a[3] == 0).all() and (c[3] == 0).all()
+                assert np.array_equal(a[1].view(np.uint32), c[1].view(np.uint32))
+                for p in range(len(qs)):
+                    for x, y in zip(a[0][p], c[0][p]):
+                        assert np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32)), (mode, variant, ks, p)
+                    assert np.array_equal(a[2][p], c[2][p])
             D, PQ, PT = c[0][6]
             assert np.array_equal(D.view(np.uint32), D0.view(np.uint32)) and np.array_equal(PQ, PQ0) and np.array_equal(PT, PT0)

@@ -77,8 +77,8 @@ def test_c2_planes_and_optimal_equal_the_reference(kernel, blosum62):
     for g, q, t in zip(gold, qs, ts):
         assert hashlib.sha256(q.encode()).hexdigest() == g["q_sha"] and hashlib.sha256(t.encode()).hexdigest() == g["t_sha"]
     ctx = gpu_util.ctx()
-    hints = {"tag": {"tag_segments": 0}, "tag_segq": {"tag_segments": 2},
-             "tag_nw1": {"dp_variant_nw": 1, "dp_variant_r": 4, "dp_variant_x": 8, "tag_segments": 2}, "int": {"tag_kernel": 0}}[kernel]
+    hints = {"tag": {"tag_segments": 0}, "tag_segq": {"tag_segments": -6},
+             "tag_nw1": {"dp_variant_nw": 1, "dp_variant_r": 4, "dp_variant_x": 8, "tag_segments": -6}, "int": {"tag_kernel": 0}}[kernel]
     with ctx.hints(**hints):
         b = aln_amd.Batch(ctx, list(qs), list(ts))
         b.dp_submatrix(alpha, table, aln_amd.LOCAL, 11, 1, aln_amd.FWD, aln_amd.DP_FAST)
@@ -223,3 +223,52 @@ def test_c5_block_equals_the_reference(blosum62):
     with ctx.hints(score_packed=0):
         got = aln_amd.score_all_vs_all(ctx, seqs, seqs, alpha, table, 11, 1)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def long_pair(g):
+    if g["homolog"]:
+        q, t = homolog_pair(g["seed"], max(g["qlen"], g["tlen"]))
+        return q[:g["qlen"]], t[:g["tlen"]]
+    return random_pair(g["seed"], g["qlen"], g["tlen"])
+
+
+@pytest.mark.parametrize("kernel", ["tag", "int", "exact"])
+def test_pairs_beyond_2048_residues_equal_the_reference(kernel, blosum62):
+    """The reference has no length limit (dpmatrix.h:250-259).  Pairs between 2049 and 4094 residues, local 11/1: the tagged
+    kernel's 12-tag-bit layout (one instantiation, 4 waves x 1024 columns, pointer dialect 2), the untagged O(n^2) kernel
+    and the exact-order tiled kernel against sha256 of the reference's planes + its Optimal alignment."""
+    alpha, table = blosum62
+    gold = doc()["long"]["pairs"]
+    prs = [long_pair(g) for g in gold]
+    for g, (q, t) in zip(gold, prs):
+        assert hashlib.sha256(q.encode()).hexdigest() == g["q_sha"] and hashlib.sha256(t.encode()).hexdigest() == g["t_sha"]
+    ctx = gpu_util.ctx()
+    hints = {"tag": {}, "int": {"tag_kernel": 0}, "exact": {}}[kernel]
+    with ctx.hints(**hints):
+        b = aln_amd.Batch(ctx, [p[0] for p in prs], [p[1] for p in prs])
+        b.dp_submatrix(alpha, table, aln_amd.LOCAL, 11, 1, aln_amd.FWD, aln_amd.DP_EXACT if kernel == "exact" else aln_amd.DP_FAST)
+    kn = b.kernel_name()
+    if kernel == "tag":
+        assert kn.startswith("dp_affine_tag") and "NW=4,R=2,X=8" in kn and "tag12" in kn, kn
+        assert b.plane_bytes_per_cell() == 4
+    elif kernel == "int":
+        assert kn.startswith("dp_affine_int"), kn
+    else:
+        assert "dp_exact_tiled" in kn, kn
+    scores, lists, status = b.optimal()
+    assert (status == 0).all()
+    for k, g in enumerate(gold):
+        check_planes(b, k, g, "%s %s" % (kn, g["name"]))
+        check_opt(g, scores[k], lists[k], "%s %s" % (kn, g["name"]))
+    if kernel == "tag":                                   # near-optimal enumeration reads the 12-bit pointer words too
+        flags = make_subopt_regions(len(prs[0][1]) + 2, 6)
+        with ctx.hints(tag_kernel=0):
+            b2 = aln_amd.Batch(ctx, [prs[0][0]], [prs[0][1]])
+            b2.dp_submatrix(alpha, table, aln_amd.LOCAL, 11, 1, aln_amd.FWD, aln_amd.DP_FAST)
+        e1 = b.enumerate(0, "cw", 40, 0.002, flags)
+        e2 = b2.enumerate(0, "cw", 40, 0.002, flags)
+        assert len(e1) == len(e2) >= 2
+        for x, y in zip(e1, e2):
+            assert bits(x["score"]) == bits(y["score"]) and np.array_equal(x["pairs"], y["pairs"])
+        b2.close()
+    b.close()
