@@ -121,6 +121,8 @@ int aln_batch_create(aln_ctx* ctx, const aln_seqs* queries, const aln_seqs* temp
   b->t_res.assign(templates->residues, templates->residues + b->t_total);
   b->h_pairs.resize(n_pairs);
   b->maxQ = 0; b->maxT = 0; b->cells = 0;
+  int row_align = ctx->hints.plane_row_align;
+  if (row_align != 16 && row_align != 32 && row_align != 64) row_align = 8;
   int64_t off = 0;
   for (int p = 0; p < n_pairs; ++p) {
     int qi = q_idx[p], ti = t_idx[p];
@@ -129,7 +131,8 @@ int aln_batch_create(aln_ctx* ctx, const aln_seqs* queries, const aln_seqs* temp
     int64_t Q = b->q_offsets[qi + 1] - b->q_offsets[qi], T = b->t_offsets[ti + 1] - b->t_offsets[ti];
     if (Q < 2 || T < 2) { delete b; return ALN_E_ARG; }          // every sequence carries '^' and '$'
     if (Q > kMaxLen || T > kMaxLen) { delete b; return ALN_E_TOO_LONG; }
-    d.Q = (int)Q; d.T = (int)T; d.ld = row_stride((int)T);
+    d.Q = (int)Q; d.T = (int)T; d.ld = row_stride((int)T, row_align);
+    b->maxld = std::max(b->maxld, d.ld);
     d.q_seq = qi; d.t_seq = ti;
     d.q_off = b->q_offsets[qi]; d.t_off = b->t_offsets[ti];
     d.plane_off = off;
@@ -169,7 +172,7 @@ void aln_batch_destroy(aln_batch* b) {
   if (!b) return;
   hipFree(b->d_pairs); hipFree(b->d_qcodes); hipFree(b->d_tcodes); hipFree(b->d_H); hipFree(b->d_P); hipFree(b->d_S);
   hipFree(b->d_res); hipFree(b->d_table32); hipFree(b->d_tablef); hipFree(b->d_tgi); hipFree(b->d_tge);
-  hipFree(b->d_path); hipFree(b->d_bounds); hipFree(b->d_xscratch); hipFree(b->d_tagq); hipFree(b->d_tagstate); hipFree(b->d_tcn); hipFree(b->d_deltab); hipFree(b->d_deltab_off); hipFree(b->d_instab);
+  hipFree(b->d_path); hipFree(b->d_bounds); hipFree(b->d_xscratch); hipFree(b->d_tagq); hipFree(b->d_tagstate); hipFree(b->d_deltabR); hipFree(b->d_pair_deloff); hipFree(b->d_tcn); hipFree(b->d_deltab); hipFree(b->d_deltab_off); hipFree(b->d_instab);
   for (int k = 0; k < 2; ++k) { if (b->h_slot[k]) hipHostFree(b->h_slot[k]); if (b->slot_ev[k]) hipEventDestroy(b->slot_ev[k]); }
   for (int k = 0; k < aln_batch::kEvRing; ++k) { if (b->ring0[k]) hipEventDestroy(b->ring0[k]); if (b->ring1[k]) hipEventDestroy(b->ring1[k]); }
   delete b;
@@ -283,6 +286,8 @@ int upload_tgaps(aln_batch* b, const aln_gap* gap) {
       total += T * T;
     }
     if (gn2 && !b->d_tcn) { int rc = dalloc(ctx, &b->d_tcn, (size_t)b->t_total); if (rc) return rc; }
+    b->deltabR_valid = false;
+    if (b->d_deltabR) { hipFree(b->d_deltabR); b->d_deltabR = nullptr; }
     if (b->d_deltab) { hipFree(b->d_deltab); b->d_deltab = nullptr; }
     if (b->d_deltab_off) { hipFree(b->d_deltab_off); b->d_deltab_off = nullptr; }
     { int rc = dalloc(ctx, &b->d_deltab, (size_t)std::max<int64_t>(total, 1)); if (rc) return rc; }

@@ -15,9 +15,10 @@ constexpr uint32_t kNullPtr = 0xFFFFFFFFu;   // packed (prev_q<<16 | prev_t) of 
 constexpr int kMaxLen = 65534;               // 16-bit packed indices, 0xFFFF reserved for DPCell::null
 constexpr int kCodeHead = 30, kCodeTail = 31;   // residue codes of '^' and '$'; alphabet codes are 0..n-1 (n <= 30)
 constexpr int kNeg = -(1 << 28);             // "-infinity" of the integer kernels (leaves headroom for subtractions)
-// Row stride of a pair's planes in cells: T rounded up to 8, so fp32 rows are 32-byte and uint16 rows 16-byte aligned and a
-// lane's 8-cell store never straddles the end of a row.
-inline int row_stride(int T) { return (T + 7) & ~7; }
+// Row stride of a pair's planes in cells: T rounded up to `align` cells (a power of two >= 8; context hint "plane_row_align").
+// 8: fp32 rows are 32-byte and uint16 rows 16-byte aligned and a lane's 8-cell store never straddles the end of a row.
+// 64: uint16 rows start on 128-byte lines, so every wave-wide store covers whole cache lines.
+inline int row_stride(int T, int align) { return (T + align - 1) & ~(align - 1); }
 
 // One DPMatrix of the batch, as the kernels see it.
 struct PairDesc {
@@ -72,6 +73,7 @@ struct aln_hints {
   int exact_literal = 0;     // 1: the literal O(n^3) kernel everywhere
   int exact_alt_prio = 1;    // tiled exact kernel: priority rotation over the 4 resident waves
   int score_packed = 1;      // 0: one query per wave in aln_score_all_vs_all
+  int plane_row_align = 8;   // cells a plane row is padded to when a batch is created (8, 16, 32 or 64)
   int64_t enum_node_cap = 0; // trie nodes of aln_batch_enumerate (0 = default)
   int enum_pool_retries = 2; // aln_batch_enumerate_all: times a pair whose pools overflowed is searched again with 4 x the capacity
 };
@@ -95,6 +97,7 @@ struct aln_batch {
   std::string q_res, t_res;                    // host copies of residues (for host-side helpers / lowering)
   int64_t q_total, t_total;
   int32_t maxQ, maxT;
+  int32_t maxld = 0;                           // largest row stride of a pair
   int64_t plane_elems;
   int64_t cells;                               // sum (Q-2)(T-2)
   // device
@@ -107,6 +110,8 @@ struct aln_batch {
   float* d_tgi; float* d_tge;                  // AFFINE_TPOS_MIN arrays (template pool positions)
   float* d_tcn = nullptr; float* d_deltab = nullptr; int64_t* d_deltab_off = nullptr;   // DEL_TABLE_INS_TPOS (Gn2Eval), TABLES
   float* d_instab = nullptr;                                                            // TABLES
+  float* d_deltabR = nullptr; bool deltabR_valid = false;     // DEL_TABLE_INS_TPOS, reverse builds: flipped transposes of the tables
+  int64_t* d_pair_deloff = nullptr;                           // ... first element of every PAIR's table
   int32_t n_tseqs = 0;
   int32_t* d_path;                             // traceback output, n_pairs x path_stride x 2
   int32_t path_stride;

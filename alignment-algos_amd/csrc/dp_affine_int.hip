@@ -407,7 +407,7 @@ int launch_dp_affine_int(aln_batch* b, bool use_simplane) {
   prm.ge = (int)b->gap.gap_extn;
   prm.free_del = b->gapdev.free_del;
   prm.free_ins = b->gapdev.free_ins;
-  const int ld = row_stride(b->maxT);
+  const int ld = b->maxld;
   // variant choice: columns covered = 256 * R * NW >= ld.  Prefer several waves per pair (VALU issue needs >= 2 waves
   // per SIMD; one barrier per row is cheap) — overridable for tuning with ALN_DP_VARIANT="NW,R".
   int nw = b->ctx->hints.dp_nw, r = b->ctx->hints.dp_r;

@@ -635,12 +635,12 @@ static int launch_tag_variant(aln_batch* b, const TagParams& prm_in) {
   prm.n_pairs = b->n_pairs; prm.queue = nullptr;
   prm.ksegs = std::min(std::abs(want), kSegs);
   bool segq = false;
-  if (prm.ksegs >= 2 && (want < 0 || (b->n_pairs >= 512 && R * X == 16))) {
+  if (prm.ksegs >= 1 && (want < 0 || (b->n_pairs >= 512 && R * X == 16))) {      // (1: the queue kernel with whole pairs — diagnosis only)
     long items = 0;
     for (const PairDesc& d : b->h_pairs) items += seg_count(d.Q, prm.ksegs);
-    if (items > b->n_pairs) {
+    if (items > b->n_pairs || prm.ksegs == 1) {
       constexpr size_t kStateBytes = (size_t)((2 * R * X + R + 2 + 3) / 4) * 16 * 64 * NW;
-      const size_t qbytes = ((size_t)(16 + (items - b->n_pairs)) * 4 + 15) & ~(size_t)15;
+      const size_t qbytes = ((size_t)(16 + std::max<long>(items - b->n_pairs, 4)) * 4 + 15) & ~(size_t)15;
       const size_t sbytes = (size_t)b->n_pairs * kSegs * kStateBytes;
       if (b->tagq_bytes < qbytes || b->tagstate_bytes < sbytes) {
         ALN_HIP_CHECK(b->ctx, hipStreamSynchronize(st));
@@ -688,7 +688,7 @@ int launch_dp_affine_tag(aln_batch* b) {
   prm.alt_prio = b->ctx->hints.tag_alt_prio;
   prm.lag = b->ctx->hints.tag_lag;
   if (prm.lag < 0 || prm.lag > 4 || (prm.lag & (prm.lag - 1))) prm.lag = 0;      // 0, 1, 2 or 4: lag * (NW-1) + lag <= 16 slots for NW <= 4
-  const int ld = row_stride(b->maxT);
+  const int ld = b->maxld;
   // variant = waves per pair, groups per lane, consecutive columns a lane owns in a group (ALN_DP_VARIANT="NW,R[,X]")
   int nw = b->ctx->hints.dp_nw, r = b->ctx->hints.dp_r, x = b->ctx->hints.dp_x ? b->ctx->hints.dp_x : 4;
   // sequences beyond 2048 need 12 tag bits (pointer dialect 2): one instantiation, 4 waves x 2 groups x 8 columns = 4096 columns

@@ -506,17 +506,27 @@ constexpr int kTW = 256;       // tile width = threads
 constexpr int kTRing = 32;     // frame-ordered copies of finished rows kept per workgroup (>= kBR + 1)
 constexpr int kTLoc = 320;     // tile-local row buffer: 257 live entries + pads the masked tail may read
 
-template <int PT, bool TPOS, bool LOCAL>
+// GM = gap model: 0 constant affine (aasubalib.h:27-77), 1 min(t1,t2) position coefficients (hmap2_eval.h:41-95), 2 Gn2Eval's
+// model (gn2_eval.h:100-165): deletion(t1,t2) read from a per-template T x T table — it depends on the two template positions
+// only, so one loaded value serves the 16 rows of a block exactly like a computed one — and insertion(dist) =
+// (gi[t1] + ge[t1] * (dist - 2)) + cn[t1] with the coefficients of the SMALLER template position alone.
+// `delF`: GM 2 only; entry [k * pitch + b] of pair p's table at delF_off[p] is the deletion between FRAME columns k < b
+// (forward builds: the caller's table; reverse builds: its flipped transpose, see launch_dp_exact_blocked).
+template <int PT, int GM, bool LOCAL>
 __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* __restrict__ pairs, EvalDev proto,
                                                                  const uint8_t* __restrict__ qcodes, const uint8_t* __restrict__ tcodes,
                                                                  const float* __restrict__ tgi, const float* __restrict__ tge,
                                                                  float* __restrict__ Hbase, uint32_t* __restrict__ Pbase,
                                                                  const float* __restrict__ Sbase, PairResult* __restrict__ res, int rev,
-                                                                 float* __restrict__ scratch_base, int alt_prio) {
+                                                                 float* __restrict__ scratch_base, int alt_prio,
+                                                                 const float* __restrict__ delF_base, const int64_t* __restrict__ delF_off) {
+  constexpr bool TPOS = GM == 1;
+  constexpr bool TAB = GM == 2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float2* tg = reinterpret_cast<float2*>(lds);          // (tgi, tge) in frame order, PT entries
   float* rowloc0 = lds + 2 * PT;                         // rows a-1 / a of the current tile, index k - kbase
   float* rowloc1 = rowloc0 + kTLoc;
+  float* tcnl = rowloc1 + kTLoc;                         // GM 2: Gn2Eval's v_cn in frame order, PT entries
   __shared__ float red_v[kTW / 64];
   __shared__ uint32_t red_p[kTW / 64];
   const float ninf = -__builtin_inff();
@@ -528,6 +538,7 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
   e.tc = tcodes ? tcodes + pd.t_off : nullptr;
   e.tgi = tgi ? tgi + pd.t_off : nullptr;
   e.tge = tge ? tge + pd.t_off : nullptr;
+  bind_table_model(e, proto, pd);
   e.S = Sbase ? Sbase + pd.plane_off : nullptr;
   float* __restrict__ H = Hbase + pd.plane_off;
   uint32_t* __restrict__ P = Pbase + pd.plane_off;
@@ -536,6 +547,12 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
   const int nQ = f.nQ(), nT = f.nT();
   const int tid = threadIdx.x, wave = tid >> 6;
   const float gi_c = e.gi, ge_c = e.ge;
+  // GM 2: the frame-ordered deletion table of this pair, pitch = the template's real length; frame column 0 = real t0 (forward)
+  // or t1 (reverse, in the flipped table: index T-1-t1)
+  const int TT = pd.T;
+  const float* __restrict__ delF = nullptr;
+  if (TAB) delF = delF_base + delF_off[blockIdx.x] + (size_t)(rev ? (pd.T - 1 - pd.t1) : pd.t0) * (size_t)(TT + 1);
+  auto del_at = [&](int k, int b) -> float { return delF[(size_t)(k < TT ? k : TT - 1) * TT + b]; };   // k clamped: masked candidates only
   // per-workgroup scratch: far-insertion and far-left-deletion results [2][3][kBR][PT] (own words only, read back through L2),
   // finished rows in frame order [kTRing][PT], (tgi, tge) [2][PT]
   float* scr_m = scratch_base + (size_t)blockIdx.x * (size_t)(6 * kBR + kTRing + 2) * PT;
@@ -554,9 +571,10 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
   if (nQ >= 2 && nT >= 2) {
     for (int x = tid; x < PT; x += kTW) {
       float2 v = {0.f, 0.f};
-      if (TPOS && x <= nT) { const int pos = f.rt(x); v.x = e.tgi[pos]; v.y = e.tge[pos]; }
+      if ((TPOS || TAB) && x <= nT) { const int pos = f.rt(x); v.x = e.tgi[pos]; v.y = e.tge[pos]; }
       tg[x] = v;
       tgiF[x] = v.x; tgeF[x] = v.y;
+      if (TAB) tcnl[x] = (x <= nT) ? e.tcn[f.rt(x)] : 0.f;
     }
     for (int x = tid; x < 2 * kTLoc; x += kTW) rowloc0[x] = ninf;
     __threadfence_block();
@@ -585,8 +603,9 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
         // ============ far insertions of rows a0 .. a0+15 for column bc: candidates k = 1 .. a0-2 =====================
         if (a0 >= 3 && wave_on) {
           const int b = (bc < 2 || !bv) ? 2 : bc;
-          float gi = gi_c, ge = ge_c;
+          float gi = gi_c, ge = ge_c, cn = 0.f;
           if (TPOS) { const float2 t0 = tg[b - 1], t1 = tg[b]; gi = fminr(t0.x, t1.x); ge = fminr(t0.y, t1.y); }
+          if (TAB) { const int lo = rev ? b : b - 1; const float2 t = tg[lo]; gi = t.x; ge = t.y; cn = tcnl[lo]; }   // the smaller real position
           const size_t colb = (size_t)f.rt(b - 1);
           constexpr int HW = kBR / 2;                  // two 8-row windows: half the registers of one 16-row window
 #pragma unroll 1
@@ -594,7 +613,11 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
             float W[HW], cm[HW], m[HW], ee[HW]; int cc[HW];
             float fn = (float)(a0 + HW * h - 2);       // n of (row a0 + 8h, k = 0)
 #pragma unroll
-            for (int i = 0; i < HW; ++i) { W[i] = gi + ge * (fn + (float)i); cm[i] = ninf; m[i] = ninf; ee[i] = ninf; cc[i] = 0; }
+            for (int i = 0; i < HW; ++i) {
+              W[i] = gi + ge * (fn + (float)i);
+              if (TAB) W[i] = W[i] + cn;                    // gn2_eval.h: gp = gi + ge * (di - 2); gp = gp + cn
+              cm[i] = ninf; m[i] = ninf; ee[i] = ninf; cc[i] = 0;
+            }
             for (int kc = 0; kc <= a0 - 2; kc += kBR) {
               float x[kBR];
 #pragma unroll
@@ -609,7 +632,7 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
                   submax4_vv(cm[r], cm[r + 1], cm[r + 2], cm[r + 3], x[u], W[(r - u) & (HW - 1)], W[(r + 1 - u) & (HW - 1)],
                              W[(r + 2 - u) & (HW - 1)], W[(r + 3 - u) & (HW - 1)]);
                 fn -= 1.0f;
-                W[(HW - 1 - u) & (HW - 1)] = gi + ge * fn;
+                W[(HW - 1 - u) & (HW - 1)] = TAB ? (gi + ge * fn) + cn : gi + ge * fn;
               }
 #pragma unroll
               for (int r = 0; r < HW; ++r) {
@@ -649,12 +672,17 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
               sload_rows<0, kBR, PT>(src, sbase + k);
               f4v gk = {0.f, 0.f, 0.f, 0.f}, ek = {0.f, 0.f, 0.f, 0.f};
               if (TPOS) { gk = sload4_imm<0>(tgiF + k); ek = sload4_imm<PT * 4>(tgiF + k); }
+              float gt[4] = {0.f, 0.f, 0.f, 0.f};
+              if (TAB) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) gt[u] = delF[(size_t)(k + u) * TT + b];      // k + u < kbase <= b - 1: inside the table
+              }
               swait_lgkm0();
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
                 const float gi = TPOS ? vmin_sv(gk[u], gib) : gi_c;
                 const float ge = TPOS ? vmin_sv(ek[u], geb) : ge_c;
-                const float g = gi + ge * fd;
+                const float g = TAB ? gt[u] : gi + ge * fd;
                 fd -= 1.0f;
                 if (k + u == 0) continue;              // column 0 is never a source (dpmatrix.h:459 starts at t0+1)
 #pragma unroll
@@ -719,8 +747,26 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
               if (cb >= 1) { s.m[0] = aload(&fdm[r * PT + bb]); s.e[0] = aload(&fde[r * PT + bb]); s.cidx[0] = aloadi(&fdc[r * PT + bb]); }
               else { s.m[0] = ninf; s.e[0] = ninf; s.cidx[0] = 0; }
               const int tail = kbase + 64 * wave;
-              scan_range<0, 1, TPOS, false>(s, prev, tg, kbase, tail, gi_c, ge_c);
-              scan_range<0, 1, TPOS, true>(s, prev, tg, tail, tail + 64, gi_c, ge_c);
+              if constexpr (TAB) {
+                // the tile's own source columns: one table value per candidate, same 32-column chunks and (max, e, chunk) bookkeeping
+                for (int kc = kbase; kc < tail + 64; kc += kBC) {
+                  float cmx = ninf;
+#pragma unroll 8
+                  for (int u = 0; u < kBC; ++u) {
+                    const int k = kc + u;
+                    float d = prev[k] - del_at(k, bb);
+                    d = (k <= bb - 2) ? d : ninf;
+                    cmx = vmaxf(cmx, d);
+                  }
+                  const bool up = cmx > s.m[0];
+                  s.e[0] = up ? s.m[0] : s.e[0];
+                  s.cidx[0] = up ? kc : s.cidx[0];
+                  s.m[0] = up ? cmx : s.m[0];
+                }
+              } else {
+                scan_range<0, 1, TPOS, false>(s, prev, tg, kbase, tail, gi_c, ge_c);
+                scan_range<0, 1, TPOS, true>(s, prev, tg, tail, tail + 64, gi_c, ge_c);
+              }
               const float dm = s.m[0], de = s.e[0]; const int dc = s.cidx[0];
               // ---- insertions ---------------------------------------------------------------------------------------
               const size_t colb = (size_t)f.rt(bb - 1);
@@ -736,13 +782,15 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
               if (sd > opt) { opt = sd; cat = 1; }
               const float sfar = clip0(mf + sim, LOCAL);
               float snear = ninf; int knear = 0;
-              float gi = gi_c, ge = ge_c;
+              float gi = gi_c, ge = ge_c, cn = 0.f;
               if (TPOS) { const float2 t0 = tg[bb - 1], t1 = tg[bb]; gi = fminr(t0.x, t1.x); ge = fminr(t0.y, t1.y); }
+              if (TAB) { const int lo = rev ? bb : bb - 1; const float2 t = tg[lo]; gi = t.x; ge = t.y; cn = tcnl[lo]; }
+              auto ins_gap = [&](int n) -> float { float g = gi + ge * (float)n; if (TAB) g = g + cn; return g; };
 #pragma unroll
               for (int u = 0; u < kBR; ++u) {
                 if (kn0 + u <= a - 2) {
                   float sv = xn[u];
-                  sv -= gi + ge * (float)(a - (kn0 + u) - 2);
+                  sv -= ins_gap(a - (kn0 + u) - 2);
                   sv += sim;
                   sv = clip0(sv, LOCAL);
                   if (sv > snear) { snear = sv; knear = kn0 + u; }
@@ -758,7 +806,8 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
                 const float* prevF = rowsF + (size_t)((a - 1) & (kTRing - 1)) * PT;   // row a-1, every column, through L2
                 auto lit = [&](int kk, float pvv) -> float {
                   const float2 tk = tg[kk];
-                  const float g = (TPOS ? fminr(tk.x, gbi) : gi_c) + (TPOS ? fminr(tk.y, gbe) : ge_c) * (float)(bb - kk - 2);
+                  float g = (TPOS ? fminr(tk.x, gbi) : gi_c) + (TPOS ? fminr(tk.y, gbe) : ge_c) * (float)(bb - kk - 2);
+                  if (TAB) g = del_at(kk, bb);
                   float sv = pvv;
                   sv -= g;
                   sv += sim;
@@ -793,7 +842,7 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
                   for (int u = 0; u < kBR; ++u) {
                     if (!found && k + u <= a0 - 2) {
                       float sv = xs[u];
-                      sv -= gi + ge * (float)(a - (k + u) - 2);
+                      sv -= ins_gap(a - (k + u) - 2);
                       sv += sim;
                       sv = clip0(sv, LOCAL);
                       if (sv == opt) { found = true; oa = k + u; }
@@ -803,7 +852,7 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
                 } else {
                   for (; k < a0 - 2; ++k) {
                     float sv = aload(&H[(size_t)f.rq(k) * ld + colb]);
-                    sv -= gi + ge * (float)(a - k - 2);
+                    sv -= ins_gap(a - k - 2);
                     sv += sim;
                     sv = clip0(sv, LOCAL);
                     if (sv == opt) break;
@@ -879,7 +928,19 @@ static size_t blocked_scratch_floats(int ns) { return (size_t)3 * kBR * (ns * 25
 bool dp_exact_blocked_legal(const aln_batch* b) {
   int mx = 0;
   for (const PairDesc& d : b->h_pairs) { const int nT = d.t1 - d.t0; if (nT - 1 > mx) mx = nT - 1; }
-  return mx <= 16 * 256 && b->gapdev.model != ALN_GAP_DEL_TABLE_INS_TPOS && b->gapdev.model != ALN_GAP_TABLES;   // the table model runs in the literal kernel
+  return mx <= 16 * 256 && b->gapdev.model != ALN_GAP_TABLES;   // a plugin's fully tabulated gap functions run in the literal kernel
+}
+
+// tabR[x][y] = tab[T-1-y][T-1-x]: the deletion table of a template as a REVERSE build's frame sees it
+__global__ void flip_transpose_kernel(const float* __restrict__ tab, float* __restrict__ tabR, int T) {
+  __shared__ float tile[16][17];
+  const int x0 = blockIdx.y * 16, y0 = blockIdx.x * 16;          // output tile: rows x0.., columns y0..
+  // source element of output (x, y) is tab[T-1-y][T-1-x]: read with the source's column index (T-1-x) running over threadIdx.x
+  const int sy = T - 1 - (y0 + threadIdx.y), sx = T - 1 - (x0 + threadIdx.x);
+  if (sy >= 0 && sx >= 0) tile[threadIdx.y][threadIdx.x] = tab[(size_t)sy * T + sx];
+  __syncthreads();
+  const int x = x0 + threadIdx.y, y = y0 + threadIdx.x;
+  if (x < T && y < T) tabR[(size_t)x * T + y] = tile[threadIdx.x][threadIdx.y];
 }
 
 int launch_dp_exact_blocked(aln_batch* b) {
@@ -888,7 +949,8 @@ int launch_dp_exact_blocked(aln_batch* b) {
   for (const PairDesc& d : b->h_pairs) { const int nT = d.t1 - d.t0; if (nT - 1 > mx) mx = nT - 1; }
   const int ns = mx <= 256 ? 1 : mx <= 512 ? 2 : mx <= 1024 ? 4 : 8;
   // templates wider than two tiles: the tiled kernel shares the far-left deletion scans between 16 rows
-  const bool tiled = mx > 2 * kTW && (ctx->hints.exact_tiles || mx > 8 * kTW);   // the slot kernel ends at 8 x 256 columns
+  const bool gn2 = b->gapdev.model == ALN_GAP_DEL_TABLE_INS_TPOS;
+  const bool tiled = gn2 || (mx > 2 * kTW && (ctx->hints.exact_tiles || mx > 8 * kTW));   // the slot kernel ends at 8 x 256 columns and knows no tables
   const int ptt = (mx + 1 <= 4 * kTW ? 4 : mx + 1 <= 8 * kTW ? 8 : mx + 1 <= 12 * kTW ? 12 : 16) * kTW + kBPad;          // row pitch of the scratch rows: a compile-time constant of the kernel
   const size_t need = tiled ? (size_t)(6 * kBR + kTRing + 2) * ptt * (size_t)b->n_pairs : blocked_scratch_floats(ns) * (size_t)b->n_pairs;
   if (b->xscratch_floats < need) {
@@ -909,16 +971,46 @@ int launch_dp_exact_blocked(aln_batch* b) {
   const bool tpos = b->gapdev.model == ALN_GAP_AFFINE_TPOS_MIN;
   int rc;
   if (tiled) {
-    const size_t lds = ((size_t)2 * ptt + 2 * kTLoc) * sizeof(float);
+    const size_t lds = ((size_t)2 * ptt + 2 * kTLoc + (gn2 ? ptt : 0)) * sizeof(float);
     const int rev = (int)(b->direction == ALN_REV);
+    // Gn2Eval's model: per pair the frame-ordered deletion table.  Forward builds read the caller's tables; reverse builds their
+    // flipped transposes tabR[x][y] = tab[T-1-y][T-1-x] (made here, once per upload), so that a thread's column b stays the
+    // fastest-running index in both.
+    const float* delF = nullptr;
+    if (gn2) {
+      const int ns_t = (int)b->t_offsets.size() - 1;
+      std::vector<int64_t> toff(ns_t);
+      int64_t total = 0;
+      for (int q = 0; q < ns_t; ++q) { const int64_t T = b->t_offsets[q + 1] - b->t_offsets[q]; toff[q] = total; total += T * T; }
+      if (rev && !b->deltabR_valid) {
+        if (!b->d_deltabR) ALN_HIP_CHECK(ctx, hipMalloc((void**)&b->d_deltabR, (size_t)std::max<int64_t>(total, 1) * 4));
+        for (int q = 0; q < ns_t; ++q) {
+          const int T = (int)(b->t_offsets[q + 1] - b->t_offsets[q]);
+          hipLaunchKernelGGL(flip_transpose_kernel, dim3((T + 15) / 16, (T + 15) / 16), dim3(16, 16), 0, ctx->stream,
+                             b->d_deltab + toff[q], b->d_deltabR + toff[q], T);
+        }
+        ALN_HIP_CHECK(ctx, hipGetLastError());
+        b->deltabR_valid = true;
+      }
+      delF = rev ? b->d_deltabR : b->d_deltab;
+      if (!b->d_pair_deloff) {
+        std::vector<int64_t> poff(b->n_pairs);
+        for (int q = 0; q < b->n_pairs; ++q) poff[q] = toff[b->h_pairs[q].t_seq];
+        ALN_HIP_CHECK(ctx, hipMalloc((void**)&b->d_pair_deloff, (size_t)std::max(b->n_pairs, 1) * 8));
+        ALN_HIP_CHECK(ctx, hipMemcpy(b->d_pair_deloff, poff.data(), (size_t)b->n_pairs * 8, hipMemcpyHostToDevice));
+      }
+      proto.tcn = b->d_tcn; proto.deltab = b->d_deltab; proto.deltab_off = b->d_deltab_off;
+    }
     const int alt_prio = ctx->hints.exact_alt_prio;      // aln_ctx_set_hint "exact_alt_prio"
-#define ALN_TLAUNCH(PTC, TP, LC)                                                                                                 \
-    hipLaunchKernelGGL((dp_exact_tiled_kernel<PTC, TP, LC>), dim3(b->n_pairs), dim3(kTW), lds, ctx->stream, b->d_pairs, proto,     \
-                       sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr,                        \
-                       tpos ? b->d_tge : nullptr, b->d_H, b->d_P, sub ? nullptr : b->d_S, b->d_res, rev, b->d_xscratch, alt_prio)
+#define ALN_TLAUNCH(PTC, GM_, LC)                                                                                                \
+    hipLaunchKernelGGL((dp_exact_tiled_kernel<PTC, GM_, LC>), dim3(b->n_pairs), dim3(kTW), lds, ctx->stream, b->d_pairs, proto,    \
+                       sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, (tpos || gn2) ? b->d_tgi : nullptr,               \
+                       (tpos || gn2) ? b->d_tge : nullptr, b->d_H, b->d_P, sub ? nullptr : b->d_S, b->d_res, rev, b->d_xscratch,   \
+                       alt_prio, delF, b->d_pair_deloff)
 #define ALN_TLAUNCH_P(PTC)                                                                                                       \
-    do { if (tpos) { if (b->islocal) ALN_TLAUNCH(PTC, true, true); else ALN_TLAUNCH(PTC, true, false); }                         \
-         else { if (b->islocal) ALN_TLAUNCH(PTC, false, true); else ALN_TLAUNCH(PTC, false, false); } } while (0)
+    do { if (gn2) { if (b->islocal) ALN_TLAUNCH(PTC, 2, true); else ALN_TLAUNCH(PTC, 2, false); }                                \
+         else if (tpos) { if (b->islocal) ALN_TLAUNCH(PTC, 1, true); else ALN_TLAUNCH(PTC, 1, false); }                          \
+         else { if (b->islocal) ALN_TLAUNCH(PTC, 0, true); else ALN_TLAUNCH(PTC, 0, false); } } while (0)
     if (ptt == 4 * kTW + kBPad) ALN_TLAUNCH_P(4 * kTW + kBPad);
     else if (ptt == 8 * kTW + kBPad) ALN_TLAUNCH_P(8 * kTW + kBPad);
     else if (ptt == 12 * kTW + kBPad) ALN_TLAUNCH_P(12 * kTW + kBPad);
@@ -926,7 +1018,7 @@ int launch_dp_exact_blocked(aln_batch* b) {
 #undef ALN_TLAUNCH_P
 #undef ALN_TLAUNCH
     ALN_HIP_CHECK(ctx, hipGetLastError());
-    b->kernel_name = std::string("dp_exact_tiled_kernel<") + (tpos ? "tpos," : "const,") + (b->islocal ? "local" : "global") +
+    b->kernel_name = std::string("dp_exact_tiled_kernel<") + (gn2 ? "gn2tab," : tpos ? "tpos," : "const,") + (b->islocal ? "local" : "global") +
                      (b->direction == ALN_REV ? ",rev>" : ",fwd>");
     return ALN_OK;
   }

@@ -227,7 +227,7 @@ int launch_sim_hmap2(aln_batch* b, const aln_sim* sim) {
   HTRY(hipMemcpyAsync(dt_aa, sim->t_prof.aa, nt * 80, hipMemcpyHostToDevice, ctx->stream));
   HTRY(hipMemcpyAsync(dt_sse, sim->t_prof.sse, nt * 12, hipMemcpyHostToDevice, ctx->stream));
   HTRY(hipMemcpyAsync(dt_conf, sim->t_prof.conf, nt * 4, hipMemcpyHostToDevice, ctx->stream));
-  const int ldmax = row_stride(b->maxT);
+  const int ldmax = b->maxld;
   dim3 g1((ldmax + kSimThreads - 1) / kSimThreads, (b->maxQ + kSimRows - 1) / kSimRows, b->n_pairs);
   hipLaunchKernelGGL(hmap2_sim_kernel, g1, dim3(kSimThreads), 0, ctx->stream, b->d_pairs, dq_aa, dq_sse, dq_conf, dt_aa, dt_sse,
                      dt_conf, b->d_S, sim->alpha);
