@@ -68,7 +68,7 @@ EXPORTS = [
     "aln_batch_reevaluate", "aln_batch_dp_kernel_name", "aln_batch_dp_sub", "aln_batch_get_cells", "aln_batch_get_sim",
     "aln_batch_get_corner_scores", "aln_batch_optimal", "aln_batch_optimal_enqueue", "aln_batch_optimal_collect", "aln_batch_optimal_subali", "aln_batch_enumerate", "aln_batch_enumerate_all", "aln_batch_last_enum_ms", "aln_batch_last_enum_usage", "aln_identity",
     "aln_gapped_length", "aln_gapped_strings", "aln_hmap2_gap_arrays", "aln_score_all_vs_all", "aln_batch_last_dp_ms", "aln_batch_dp_ms_history", "aln_batch_dp_algorithmic_bytes", "aln_batch_cells",
-    "aln_batch_optimal_strings", "aln_ctx_set_hint", "aln_ctx_get_hint", "aln_batch_dp_contract_bytes", "aln_batch_plane_bytes_per_cell",
+    "aln_batch_optimal_strings", "aln_batch_set_gap", "aln_ctx_set_hint", "aln_ctx_get_hint", "aln_batch_dp_contract_bytes", "aln_batch_plane_bytes_per_cell",
     "aln_deal_units", "aln_comm_unique_id", "aln_comm_create", "aln_ctx_create_multi", "aln_comm_destroy", "aln_comm_n_ranks",
     "aln_comm_last_error", "aln_gather_scores",
 ]
@@ -111,6 +111,7 @@ def lib():
         L.aln_batch_n_pairs.argtypes = [C.c_void_p]
         L.aln_batch_dp.argtypes = [C.c_void_p, C.POINTER(AlnSim), C.POINTER(AlnGap), C.c_int32, C.c_int32, C.c_int32]
         L.aln_batch_reevaluate.argtypes = [C.c_void_p]
+        L.aln_batch_set_gap.argtypes = [C.c_void_p, C.POINTER(AlnGap)]
         L.aln_batch_dp_sub.argtypes = [C.c_void_p, C.POINTER(AlnSim), C.POINTER(AlnGap), C.c_int32, _ip]
         L.aln_batch_get_cells.argtypes = [C.c_void_p, C.c_int32, _fp, _ip, _ip]
         L.aln_batch_get_sim.argtypes = [C.c_void_p, C.c_int32, _fp]
@@ -366,6 +367,11 @@ class Batch:
         g = self._gap(align_type, 0, 0, tgi, tge)
         _check(lib().aln_batch_dp(self.h, C.byref(s), C.byref(g), direction, algo, 0), self.ctx.h)
         return tgi, tge
+
+    def set_gap(self, align_type, gi=0, ge=0, tgi=None, tge=None, tcn=None, del_tables=None, ins_tables=None):
+        """aln_batch_set_gap: new gap parameters for the resident batch (similarity untouched); follow with reevaluate()."""
+        g = self._gap(align_type, gi, ge, tgi, tge, tcn, del_tables, ins_tables)
+        _check(lib().aln_batch_set_gap(self.h, C.byref(g)), self.ctx.h)
 
     def reevaluate(self):
         _check(lib().aln_batch_reevaluate(self.h), self.ctx.h)

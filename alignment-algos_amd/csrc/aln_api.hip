@@ -401,6 +401,31 @@ int aln_batch_dp(aln_batch* b, const aln_sim* sim, const aln_gap* gap, int32_t d
   return run_dp(b, integral);
 }
 
+// New gap parameters for the resident batch: the similarity source (codes + table, resident planes) stays where it is, only
+// the gap description is replaced — constants, per-position arrays, deletion / insertion tables are uploaded again.  The next
+// aln_batch_reevaluate rebuilds with them.  This is the engine-side half of the reference's refinement rounds
+// (gn2.cpp:146-185: enumerate -> templ.updateCore() -> dpm.reevaluate(), where pre_calculate derives new gap tables,
+// gn2_eval.cpp:113-158) for callers whose similarity does not change between rounds.
+int aln_batch_set_gap(aln_batch* b, const aln_gap* gap) {
+  if (!b || !gap) return ALN_E_ARG;
+  if (!b->have_dp || b->have_sub) return ALN_E_STATE;
+  aln_ctx* ctx = b->ctx;
+  ALN_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (!valid_align_type(gap->align_type)) return ALN_E_GAPSTYLE;
+  if (gap->model != ALN_GAP_AFFINE_CONST && gap->model != ALN_GAP_AFFINE_TPOS_MIN && gap->model != ALN_GAP_DEL_TABLE_INS_TPOS && gap->model != ALN_GAP_TABLES) return ALN_E_ARG;
+  ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));           // nothing may still read the tables that are replaced
+  b->gap = *gap;
+  b->islocal = gap->dp_local == 0 ? (gap->align_type == ALN_LOCAL) : (gap->dp_local == 2);
+  b->gapdev.model = gap->model;
+  b->gapdev.align_type = gap->align_type;
+  b->gapdev.gi = gap->gap_init; b->gapdev.ge = gap->gap_extn;
+  b->gapdev.free_del = (gap->align_type == ALN_LOCAL || gap->align_type == ALN_SEMI_LOCAL || gap->align_type == ALN_LOCAL_GLOBAL);
+  b->gapdev.free_ins = (gap->align_type == ALN_LOCAL || gap->align_type == ALN_SEMI_LOCAL || gap->align_type == ALN_GLOBAL_LOCAL);
+  if (gap->model != ALN_GAP_AFFINE_CONST) { const int rc = upload_tgaps(b, gap); if (rc) return rc; }
+  b->gap.t_gap_init = nullptr; b->gap.t_gap_extn = nullptr;        // host pointers are not retained
+  return ALN_OK;
+}
+
 int aln_batch_reevaluate(aln_batch* b) {
   if (!b) return ALN_E_ARG;
   if (!b->have_dp) return ALN_E_STATE;

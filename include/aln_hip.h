@@ -209,6 +209,11 @@ int aln_batch_dp(aln_batch* b, const aln_sim* sim, const aln_gap* gap,
                  int32_t direction, int32_t algo, int32_t bug_b4);
 /* DPMatrix::reevaluate (dpmatrix.h:213-218): rebuild with the parameters of the last aln_batch_dp. */
 int aln_batch_reevaluate(aln_batch* b);
+/* Replace the gap description of the resident batch (constants, per-position arrays, deletion / insertion tables are uploaded
+ * again; the similarity source stays resident); the next aln_batch_reevaluate builds with it.  The engine-side half of the
+ * reference's refinement rounds — crcno.enumerate -> templ.updateCore -> dpm.reevaluate (gn2.cpp:146-185), where pre_calculate
+ * derives new gap tables (gn2_eval.cpp:113-158) — for callers whose similarity does not change between rounds. */
+int aln_batch_set_gap(aln_batch* b, const aln_gap* gap);
 /* name of the DP kernel the last aln_batch_dp launched ("dp_affine_int<...>" / "dp_exact<...>") */
 const char* aln_batch_dp_kernel_name(const aln_batch* b);
 

@@ -395,7 +395,7 @@ def test_gn2_table_gap_model(direction):
     five end-gap styles, DP + Optimal + constrained enumeration vs the oracle's restatement.  Parity UNPINNED against the
     reference itself (Gn2Eval cannot be built without Troll); this pins kernel == oracle."""
     rng = np.random.RandomState(5)
-    dims = [(9, 14), (40, 33), (66, 90)]
+    dims = [(9, 14), (40, 33), (66, 90), (120, 300), (300, 530), (3, 258), (20, 2)]      # up to three 256-column tiles, 19 row blocks
     planes, tabs = [], []
     for (Q, T) in dims:
         S = rng.normal(0.1, 1.2, size=(Q, T)).astype(np.float32)
@@ -407,7 +407,7 @@ def test_gn2_table_gap_model(direction):
         b = aln_amd.Batch(gpu_util.ctx(), ["A" * (Q - 2) for Q, T in dims], ["A" * (T - 2) for Q, T in dims])
         dels = [gn2_deletion_table(tb, T, mode) for tb, (Q, T) in zip(tabs, dims)]
         b.dp_simmatrix(planes, mode, 0, 0, DIRS[direction], tgi=pool["v_gi"], tge=pool["v_ge"], tcn=pool["v_cn"], del_tables=dels)
-        assert "dp_exact_kernel" in b.kernel_name()
+        assert "dp_exact_tiled_kernel<gn2tab" in b.kernel_name(), b.kernel_name()
         scores, lists, status = b.optimal()
         for p, S in enumerate(planes):
             gap = orc.Gap(mode, gn2=tabs[p])
@@ -767,3 +767,56 @@ def test_segment_queue_is_invisible(blosum62):
                     assert np.array_equal(a[2][p], c[2][p])
             D, PQ, PT = c[0][6]
             assert np.array_equal(D.view(np.uint32), D0.view(np.uint32)) and np.array_equal(PQ, PQ0) and np.array_equal(PT, PT0)
+
+
+def test_gn2_rounds_set_gap_then_reevaluate():
+    """The refinement rounds of gn2.cpp:146-185 on a resident batch: aln_batch_set_gap swaps the gap tables (similarity planes stay
+    in HBM), aln_batch_reevaluate rebuilds.  Three rounds, forward and reverse, global and local: every round equals a fresh batch
+    built with that round's tables; the tiled exact kernel equals the literal O(n^3) kernel on 900 x 1100 pairs (where the
+    oracle is too slow), which in turn is oracle-checked by test_gn2_table_gap_model; constant and position gaps can be
+    swapped in the same way."""
+    rng = np.random.RandomState(11)
+    dims = [(900, 1100), (310, 700), (64, 64)]
+    planes = []
+    for (Q, T) in dims:
+        S = rng.normal(0.1, 1.2, size=(Q, T)).astype(np.float32)
+        S[0, :] = 0; S[-1, :] = 0; S[:, 0] = 0; S[:, -1] = 0
+        planes.append(S)
+    rounds = [[gn2_tables(rng, T) for (Q, T) in dims] for _ in range(3)]
+    ctx = gpu_util.ctx()
+
+    def args(tabs, mode):
+        pool = {k: np.concatenate([tb[k] for tb in tabs]) for k in ("v_gi", "v_ge", "v_cn")}
+        dels = [gn2_deletion_table(tb, T, mode) for tb, (Q, T) in zip(tabs, dims)]
+        return dict(tgi=pool["v_gi"], tge=pool["v_ge"], tcn=pool["v_cn"], del_tables=dels)
+
+    for direction in ("fwd", "rev"):
+        for mode in (1, 3):
+            b = aln_amd.Batch(ctx, ["A" * (Q - 2) for Q, T in dims], ["A" * (T - 2) for Q, T in dims])
+            b.dp_simmatrix(planes, mode, 0, 0, DIRS[direction], **args(rounds[0], mode))
+            for r in range(3):
+                if r > 0:
+                    b.set_gap(mode, 0, 0, **args(rounds[r], mode))
+                    b.reevaluate()
+                assert "dp_exact_tiled_kernel<gn2tab" in b.kernel_name()
+                with ctx.hints(exact_literal=1):
+                    f = aln_amd.Batch(ctx, ["A" * (Q - 2) for Q, T in dims], ["A" * (T - 2) for Q, T in dims])
+                    f.dp_simmatrix(planes, mode, 0, 0, DIRS[direction], **args(rounds[r], mode))
+                    assert f.kernel_name().startswith("dp_exact_kernel"), f.kernel_name()
+                for p in range(len(dims)):
+                    for x, y in zip(b.get_cells(p), f.get_cells(p)):
+                        assert np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32)), (direction, mode, r, p)
+                sb, lb, stb = b.optimal()
+                sf, lf, stf = f.optimal()
+                assert np.array_equal(sb.view(np.uint32), sf.view(np.uint32)) and all(np.array_equal(x, y) for x, y in zip(lb, lf))
+                f.close()
+            # the same call swaps in any other gap model: constant gaps on the resident planes == a fresh build
+            b.set_gap(mode, 4.73, 0.34)
+            b.reevaluate()
+            f = aln_amd.Batch(ctx, ["A" * (Q - 2) for Q, T in dims], ["A" * (T - 2) for Q, T in dims])
+            f.dp_simmatrix(planes, mode, 4.73, 0.34, DIRS[direction])
+            for p in range(len(dims)):
+                for x, y in zip(b.get_cells(p), f.get_cells(p)):
+                    assert np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32)), (direction, mode, "const", p)
+            f.close()
+            b.close()
