@@ -223,8 +223,8 @@ class Context:
             pass
 
 
-def score_all_vs_all(ctx, queries, templates, alphabet, table, gi, ge, q_begin=0, q_end=None):
-    """Optimal local scores of queries[q_begin:q_end] against every template, no planes (aln_score_all_vs_all)."""
+def score_all_vs_all(ctx, queries, templates, alphabet, table, gi, ge, q_begin=0, q_end=None, align_type=LOCAL):
+    """The score Optimal(align_type) reports for queries[q_begin:q_end] against every template, no planes (aln_score_all_vs_all)."""
     qpool = queries if isinstance(queries, SeqPool) else SeqPool(queries)
     tpool = templates if isinstance(templates, SeqPool) else SeqPool(templates)
     if q_end is None:
@@ -234,7 +234,7 @@ def score_all_vs_all(ctx, queries, templates, alphabet, table, gi, ge, q_begin=0
     sub = AlnSubmatrix(len(alphabet), ab, _f(tab))
     g = AlnGap()
     g.model = GAP_AFFINE_CONST
-    g.align_type = LOCAL
+    g.align_type = int(align_type)
     g.gap_init = float(np.float32(gi))
     g.gap_extn = float(np.float32(ge))
     out = np.empty((q_end - q_begin, len(tpool.seqs)), dtype=np.float32)

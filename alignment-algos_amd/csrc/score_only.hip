@@ -168,6 +168,167 @@ __global__ __launch_bounds__(64) void score_local_kernel(ScoreArgs a) {
 }
 
 
+// ---- the four non-local align types: the score Optimal reports is the FINAL cell's (optimal.h:56-74) ---------------------------
+// Same row sweep without the clip: values may be negative, so columns outside the interior are kept at "minus infinity"
+// instead of being masked to 0; row 1 and column 1 pay (or not: free end gaps, aasubalib.h:34-49,60-75) the gap from the origin
+// (dpmatrix.h:409-426); the final cell (dpmatrix.h:505-534) is the best of the last interior cell, a deletion from the last
+// interior row and an insertion from the last interior column, each free or priced by the align type.
+template <int R>
+__global__ __launch_bounds__(64) void score_global_kernel(ScoreArgs a, int free_del, int free_ins) {
+  __shared__ int tab[32 * 32];
+  const int lane = threadIdx.x;
+  for (int k = lane; k < 32 * 32; k += 64) tab[k] = a.table32[k];
+  __syncthreads();
+  const int ti = a.tsel[blockIdx.x], qi = a.q_begin + blockIdx.y;
+  const uint8_t* __restrict__ qc = a.qcodes + a.qoff[qi];
+  const uint8_t* __restrict__ tc = a.tcodes + a.toff[ti];
+  const int Q = (int)(a.qoff[qi + 1] - a.qoff[qi]), T = (int)(a.toff[ti + 1] - a.toff[ti]);
+  const int gi = a.gi, ge = a.ge;
+  float* out = &a.scores[(size_t)blockIdx.y * a.n_t + ti];
+  // degenerate shortcuts (dpmatrix.h:375-390): no interior row or column -> one gap from the origin, never clipped
+  if (Q == 2 || T == 2) {
+    int cost = 0;
+    if (Q == 2) { const int len = T - 2; cost = (len < 1 || free_del) ? 0 : gi + ge * (len - 1); }
+    else { const int len = Q - 2; cost = (len < 1 || free_ins) ? 0 : gi + ge * (len - 1); }
+    if (lane == 0) *out = (float)(-cost);
+    return;
+  }
+  const int cb = 4 * lane;
+  const int gime = gi - ge;
+  const int cl = T - 2;                                            // last interior column; its (wave-uniform) slot and lane
+  const int rs = cl / 256, xs = cl & 3, ls = (cl & 255) >> 2;
+
+  int code4[R][4], gec[R][4], ekc[R][4]; bool in[R][4];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const int c = cb + 256 * r + x;
+      int code = kCodeTail;
+      if (c < T) code = tc[c];
+      code4[r][x] = code * 4;
+      gec[r][x] = ge * c;
+      ekc[r][x] = ge * c + gime;
+      in[r][x] = (unsigned)(c - 1) < (unsigned)(T - 2);
+    }
+  int d[R][4], gmx[R][4], cv[R], ak[R][4];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    cv[r] = kNegS;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { d[r][x] = kNegS; gmx[r][x] = kNegS; }
+  }
+  int clast = kNegS;                                               // max over rows of D[k][T-2] (free insertions into the final cell)
+  auto tab_at = [&](int qrow, int c4) -> int {
+    return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(tab) + qrow + c4);
+  };
+  auto pick = [&](const int (&v)[R][4]) -> int {                   // this lane's value in slot (rs, xs)
+    int o = kNegS;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) o = (r == rs && x == xs) ? v[r][x] : o;
+    return o;
+  };
+  auto finish_row = [&]() {
+    int sk = kNegS;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int tk = kNegS;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int A = d[r][x] + gec[r][x];                       // non-interior cells hold "minus infinity": never a source
+        ak[r][x] = A;
+        tk = max(tk, A);
+      }
+      const int ik = wave_incl_max_s(tk);
+      const int ek = sdpp<0x138>(kNegS, ik);
+      cv[r] = max(sk, ek);
+      sk = max(sk, __builtin_amdgcn_readlane(ik, 63));
+    }
+    const int v = pick(d);
+    clast = max(clast, lane == ls ? v : kNegS);
+  };
+  {
+    // row 1 (dpmatrix.h:409-418): one deletion from the origin, free if the template's head gap is
+    const int qrow = (int)qc[1] * 128;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int c = cb + 256 * r + x;
+        const int cost = (c >= 2 && !free_del) ? gi + ge * (c - 2) : 0;
+        d[r][x] = in[r][x] ? tab_at(qrow, code4[r][x]) - cost : kNegS;
+      }
+    finish_row();
+  }
+  int qcode_next = (Q >= 4) ? (int)qc[2] : 0;
+  for (int i = 2; i <= Q - 2; ++i) {                               // dpmatrix.h:447-486
+    const int qrow = qcode_next * 128;
+    if (i + 1 <= Q - 2) qcode_next = (int)qc[i + 1];
+    const int roff = gi + ge * (i - 2);
+    const int rowB = ge * (i - 1);
+    const int col1 = free_ins ? 0 : roff;                          // column 1: one insertion from the origin (:421-426)
+    int bk[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int pv = cv[r];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int m = d[r][x];
+        const int A = ak[r][x];
+        const int e = pv - ekc[r][x];
+        const int f = gmx[r][x] - roff;
+        bk[r][x] = max(max(m, e), f);
+        pv = max(pv, A);
+        gmx[r][x] = max(gmx[r][x], m + rowB);
+      }
+    }
+    int prev_k = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int uk = sdpp<0x138>(0, bk[r][3]);
+      if (r > 0) uk = (lane == 0) ? prev_k : uk;
+      prev_k = __builtin_amdgcn_readlane(bk[r][3], 63);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int c = cb + 256 * r + x;
+        const int s = tab_at(qrow, code4[r][x]);
+        int h = ((x == 0) ? uk : bk[r][x - 1]) + s;
+        if (r == 0 && x == 1) h = (c == 1) ? s - col1 : h;
+        d[r][x] = in[r][x] ? h : kNegS;
+      }
+    }
+    finish_row();
+  }
+  // ---- the final cell (dpmatrix.h:505-534): row Q-2 is in d[], gmx holds rows <= Q-3, clast every row of column T-2 -----
+  int best = (lane == ls) ? pick(d) : kNegS;                       // match: D[Q-2][T-2] (the final cell's similarity is 0)
+  {
+    int dl = kNegS;                                                // deletion from (Q-2, k), k = 1 .. T-2 (k = T-2 costs nothing)
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int c = cb + 256 * r + x;
+        const int len = T - 2 - c;
+        const int cost = (len < 1 || free_del) ? 0 : gi + ge * (len - 1);
+        dl = max(dl, in[r][x] ? d[r][x] - cost : kNegS);
+      }
+    best = max(best, dl);
+    int il;                                                        // insertion from (k, T-2), k = 1 .. Q-2
+    if (free_ins) il = clast;
+    else {
+      const int g = pick(gmx);                                     // max over k <= Q-3 of D[k][T-2] + ge k
+      il = (lane == ls && Q >= 4) ? g - (gi + ge * (Q - 3)) : kNegS;
+    }
+    best = max(best, il);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) best = max(best, __shfl_xor(best, o));
+  if (lane == 0) *out = (float)best;
+}
+
+
 // ---- two queries per wave in packed 16-bit lanes --------------------------------------------------------------------
 // v_max_i32 issues at half rate on gfx950 and so does v_pk_max_i16 — which does two.  When every intermediate fits in 15 bits
 // (checked on the host) the low half of each register carries query A and the high half query B against the same template:
@@ -332,13 +493,17 @@ __global__ __launch_bounds__(64) void score_local_pk_kernel(ScoreArgs a, int n_r
 
 using namespace aln;
 
-// Optimal local scores of queries[q_begin .. q_end) against every template: scores[(q - q_begin) * n_t + t].
-// Replaces (q_end - q_begin) x n_t constructions of DPMatrix(q, t, AASubstitutionEval, fwd, local) + Optimal(local).
+// The score Optimal reports for queries[q_begin .. q_end) against every template: scores[(q - q_begin) * n_t + t].
+// Replaces (q_end - q_begin) x n_t constructions of DPMatrix(q, t, AASubstitutionEval, fwd, align_type) + Optimal(align_type):
+// find_max for local alignments, the final cell's score for the four other align types.
 extern "C" int aln_score_all_vs_all(aln_ctx* ctx, const aln_seqs* queries, const aln_seqs* templates, const aln_submatrix* sub,
                                     const aln_gap* gap, int32_t q_begin, int32_t q_end, float* scores) {
   if (!ctx || !queries || !templates || !sub || !gap || !scores) return ALN_E_ARG;
   if (q_begin < 0 || q_end > queries->n_seqs || q_begin > q_end) return ALN_E_ARG;
-  if (gap->model != ALN_GAP_AFFINE_CONST || gap->align_type != ALN_LOCAL) return ALN_E_ARG;   // round 1: local scores only
+  if (gap->model != ALN_GAP_AFFINE_CONST || gap->align_type < 0 || gap->align_type > 4) return ALN_E_ARG;
+  const bool local = gap->align_type == ALN_LOCAL;
+  const int free_del = (gap->align_type == ALN_LOCAL || gap->align_type == ALN_SEMI_LOCAL || gap->align_type == ALN_LOCAL_GLOBAL);
+  const int free_ins = (gap->align_type == ALN_LOCAL || gap->align_type == ALN_SEMI_LOCAL || gap->align_type == ALN_GLOBAL_LOCAL);
   if (!sub->alphabet || !sub->table || sub->n < 1 || sub->n > 30) return ALN_E_ARG;
   ALN_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const float gi = gap->gap_init, ge = gap->gap_extn;
@@ -413,7 +578,7 @@ extern "C" int aln_score_all_vs_all(aln_ctx* ctx, const aln_seqs* queries, const
   // packed 16-bit lanes (two queries per wave) when every intermediate provably fits: best local score <= maxs * min(Q,T),
   // A keys add ge * column, the "minus infinity" -12000 must stay below every real candidate and clear of wrap-around
   const double L = (double)std::max(maxQ, maxT), best = maxs * (double)std::min(maxQ, maxT);
-  const bool packed = best + ge * L + maxs < 30000.0 && ge * L + gi + maxs < 8000.0 && maxs < 2048.0 && ctx->hints.score_packed;
+  const bool packed = local && best + ge * L + maxs < 30000.0 && ge * L + gi + maxs < 8000.0 && maxs < 2048.0 && ctx->hints.score_packed;
   const dim3 block(64);
   // blockIdx.y is limited to 65535: walk the query rows in slabs.  The packed kernel pairs queries of similar length (a wave
   // runs to the longer one's last row): every slab's length order goes to the device ONCE, before the first launch, into its own
@@ -455,6 +620,18 @@ extern "C" int aln_score_all_vs_all(aln_ctx* ctx, const aln_seqs* queries, const
           case 6: hipLaunchKernelGGL(score_local_pk_kernel<6>, grid, block, 0, ctx->stream, s, nr); break;
           case 7: hipLaunchKernelGGL(score_local_pk_kernel<7>, grid, block, 0, ctx->stream, s, nr); break;
           default: hipLaunchKernelGGL(score_local_pk_kernel<8>, grid, block, 0, ctx->stream, s, nr); break;
+        }
+      } else if (!local) {
+        const dim3 grid(nc, nr);
+        switch (r) {
+          case 1: hipLaunchKernelGGL(score_global_kernel<1>, grid, block, 0, ctx->stream, s, free_del, free_ins); break;
+          case 2: hipLaunchKernelGGL(score_global_kernel<2>, grid, block, 0, ctx->stream, s, free_del, free_ins); break;
+          case 3: hipLaunchKernelGGL(score_global_kernel<3>, grid, block, 0, ctx->stream, s, free_del, free_ins); break;
+          case 4: hipLaunchKernelGGL(score_global_kernel<4>, grid, block, 0, ctx->stream, s, free_del, free_ins); break;
+          case 5: hipLaunchKernelGGL(score_global_kernel<5>, grid, block, 0, ctx->stream, s, free_del, free_ins); break;
+          case 6: hipLaunchKernelGGL(score_global_kernel<6>, grid, block, 0, ctx->stream, s, free_del, free_ins); break;
+          case 7: hipLaunchKernelGGL(score_global_kernel<7>, grid, block, 0, ctx->stream, s, free_del, free_ins); break;
+          default: hipLaunchKernelGGL(score_global_kernel<8>, grid, block, 0, ctx->stream, s, free_del, free_ins); break;
         }
       } else {
       const dim3 grid(nc, nr);

@@ -200,6 +200,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the config 3/4/5 figures and the end-to-end pass")
     ap.add_argument("--streams", "--batches", dest="batches", type=int, default=4,
                     help="HIP streams (contexts) the launches rotate over (1 = everything on one stream)")
+    ap.add_argument("--alt-prio", type=int, default=-1, help="tagged kernel's row-alternating wave priority: -1 = on for one stream, off for several")
     ap.add_argument("--split", type=int, default=2,
                     help="launches a step's batch is processed in (sub-batches of pairs/split pairs; 1 = one launch per step)")
     args = ap.parse_args()
@@ -241,7 +242,7 @@ def main():
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nb - 1)]
     ctxs = [aln_amd.Context(local_rank, st.cuda_stream) for st in streams]
     for c in ctxs:
-        c.set_hint("tag_alt_prio", 1 if nb == 1 else 0)    # the row-alternating priority pays on lone launches only
+        c.set_hint("tag_alt_prio", (1 if nb == 1 else 0) if args.alt_prio < 0 else args.alt_prio)    # pays on lone launches only
     units = {}                                              # (stream, sub-batch) -> resident batch object
     j = 0
     while (j % nb, j % split) not in units:

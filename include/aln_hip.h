@@ -285,11 +285,12 @@ int aln_batch_last_enum_usage(aln_batch* b, int32_t* alignments, int32_t* nodes)
 int aln_batch_last_enum_ms(aln_batch* b, float* search_ms, float* unroll_ms);
 
 /* ---- all-vs-all scoring without planes (BASELINE config 5) ------------------------------------ */
-/* The score Optimal(local) reports (find_max, optimal.h:90-93,108-124) for queries[q_begin..q_end) against EVERY
- * template: scores[(q - q_begin) * templates->n_seqs + t].  Replaces that many DPMatrix(q, t, AASubstitutionEval, fwd,
- * local) + Optimal constructions; nothing per cell is written to HBM.  A rank of a multi-GPU job calls it with its own
- * block of query rows.  Round 1: ALN_GAP_AFFINE_CONST with integer values, align_type ALN_LOCAL,
- * templates up to 2046 residues; anything else -> ALN_E_ARG / ALN_E_NOT_INTEGRAL / ALN_E_TOO_LONG. */
+/* The score Optimal reports — find_max for local alignments (optimal.h:90-93,108-124), the final cell's score for the four
+ * other align types (optimal.h:56-74) — for queries[q_begin..q_end) against EVERY template:
+ * scores[(q - q_begin) * templates->n_seqs + t].  Replaces that many DPMatrix(q, t, AASubstitutionEval, fwd, align_type) +
+ * Optimal constructions; nothing per cell is written to HBM.  A rank of a multi-GPU job calls it with its own block of query
+ * rows.  ALN_GAP_AFFINE_CONST with integer values (else ALN_E_NOT_INTEGRAL), templates up to 2046 residues (else
+ * ALN_E_TOO_LONG); local alignments whose values fit 15 bits run two queries per wave in packed 16-bit lanes. */
 int aln_score_all_vs_all(aln_ctx* ctx, const aln_seqs* queries, const aln_seqs* templates, const aln_submatrix* sub,
                          const aln_gap* gap, int32_t q_begin, int32_t q_end, float* scores);
 

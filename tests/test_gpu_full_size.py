@@ -223,6 +223,12 @@ def test_c5_block_equals_the_reference(blosum62):
     with ctx.hints(score_packed=0):
         got = aln_amd.score_all_vs_all(ctx, seqs, seqs, alpha, table, 11, 1)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # the four other align types: 12 x 12 blocks of the score Optimal(align_t) reports in the reference (the final cell)
+    n = g["n_other"]
+    for mode in (0, 1, 2, 4):
+        want = np.array(g["scores"][str(mode)], dtype=np.uint32).view(np.float32)
+        got = aln_amd.score_all_vs_all(ctx, seqs[:n], seqs[:n], alpha, table, 11, 1, align_type=mode)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), mode
 
 
 def long_pair(g):

@@ -53,6 +53,36 @@ def test_scores_equal_plane_path_and_oracle(tmax, blosum62):
         assert np.array_equal(aln_amd.score_all_vs_all(ctx, qs, ts, alpha, table, 11, 1), got)
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2, 4])
+def test_non_local_scores_equal_plane_path_and_oracle(mode, blosum62):
+    """The four non-local align types: aln_score_all_vs_all reports the final cell's score (what Optimal returns for them) —
+    against the resident-plane path for every pair of ragged sets around the 256-column class boundaries (empty and 1-residue
+    sequences included), gaps 11/1 and 3/0, and against the oracle on a sample."""
+    alpha, table = blosum62
+    rng = np.random.RandomState(100 + mode)
+    qlens = [0, 1, 2, 7, 64, 200, 333] + [int(rng.randint(2, 400)) for _ in range(3)]
+    tlens = [0, 1, 2, 254, 255, 256, 257, 600, 1022] + [int(rng.randint(2, 1500)) for _ in range(3)]
+    qs, ts = make_set(83000 + mode, qlens), make_set(84000 + mode, tlens)
+    qs[5] = ts[7][100:300]                                   # plant homologs: long diagonals and positive scores
+    qs[6] = ts[8][500:833]
+    ctx = gpu_util.ctx()
+    for gi, ge in ((11, 1), (3, 0)):
+        got = aln_amd.score_all_vs_all(ctx, qs, ts, alpha, table, gi, ge, align_type=mode)
+        qi, ti = np.meshgrid(np.arange(len(qs)), np.arange(len(ts)), indexing="ij")
+        b = aln_amd.Batch(ctx, qs, ts, qi.reshape(-1), ti.reshape(-1))
+        b.dp_submatrix(alpha, table, mode, gi, ge)
+        want = b.corner_scores().reshape(len(qs), len(ts))
+        b.close()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.argwhere(got != want)[:5]
+        for (i, j) in ((0, 0), (1, 1), (3, 4), (5, 7), (6, 8), (2, 3), (9, 11)):
+            S = orc.sim_submatrix(qs[i], ts[j], alpha, table)
+            rc, D, PQ, PT = orc.dp_build(S, orc.Gap(mode, gi, ge))
+            assert got[i, j] == D[-1, -1], (mode, gi, i, j)
+    blk = aln_amd.score_all_vs_all(ctx, qs, ts, alpha, table, 11, 1, 3, 8, align_type=mode)
+    full = aln_amd.score_all_vs_all(ctx, qs, ts, alpha, table, 11, 1, align_type=mode)
+    assert np.array_equal(blk, full[3:8])
+
+
 def test_score_only_rejects_what_it_cannot_do(blosum62):
     alpha, table = blosum62
     ctx = gpu_util.ctx()
