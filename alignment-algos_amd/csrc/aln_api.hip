@@ -339,7 +339,8 @@ int run_dp(aln_batch* b, bool simplane_integral) {
   }
   ALN_HIP_CHECK(ctx, hipEventRecord(b->ev0, ctx->stream));
   b->tag_segmented = false;
-  int rc = tagged ? launch_dp_affine_tag(b) : fast ? launch_dp_affine_int(b, !sub) : launch_dp_exact(b);
+  const bool solo = tagged && ctx->hints.tag_solo && dp_affine_solo_legal(b);
+  int rc = solo ? launch_dp_affine_solo(b) : tagged ? launch_dp_affine_tag(b) : fast ? launch_dp_affine_int(b, !sub) : launch_dp_exact(b);
   if (rc) return rc;
   ALN_HIP_CHECK(ctx, hipEventRecord(b->ev1, ctx->stream));
   rc = launch_dp_corner(b);

@@ -65,6 +65,7 @@ struct aln_hints {
                              // synchronous per-row exchange.  Measured on MI355X (config 2, lone launches): lag 0 3.11 ms, 1: 3.20, 2: 3.10,
                              // 4: 3.28; four overlapping streams 2.82 vs 3.38 — the waves of a pair drifting apart costs more in HBM
                              // row locality (the two halves of a plane row are written rows apart) than the barrier chain it removes
+  int tag_solo = 0;          // 1: pairs of 1025..2048 columns run in dp_affine_solo (one wave per pair, no barriers; wants >= 2048 pairs in flight)
   int tag_segments = 0;      // tagged kernel: (pair, row segment) work items handed out by a queue (dp_affine_tag.hip "Segment queue"):
                              // K in 2..8 = long pairs are cut into K segments when the batch alone fills the GPU (>= 512 pairs), -K = whenever
                              // pairs are long, 0 = one workgroup per pair
@@ -167,6 +168,9 @@ int launch_dp_affine_tag(aln_batch* b);
 bool tag_path_legal(const aln_batch* b, const float* table, int n, const aln_gap* gap);
 int tag_path_bits(const aln_batch* b, const float* table, int n, const aln_gap* gap);   // 0 (not legal), 11 or 12 tag bits
 bool tag_h16_legal(const aln_batch* b);
+// dp_affine_solo.hip
+bool dp_affine_solo_legal(const aln_batch* b);
+int launch_dp_affine_solo(aln_batch* b);
 // dp_corner.hip
 int launch_dp_corner(aln_batch* b);
 // traceback.hip

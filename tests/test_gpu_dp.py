@@ -820,3 +820,41 @@ def test_gn2_rounds_set_gap_then_reevaluate():
                     assert np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32)), (direction, mode, "const", p)
             f.close()
             b.close()
+
+
+def test_solo_kernel_vs_oracle_and_tagged(blosum62):
+    """dp_affine_solo (context hint "tag_solo": one wave per pair, strips of 512 columns visited in blocks of 16 rows, no barrier):
+    ragged batch around every strip boundary (511..513, 1023..1025, 1535..1537, 2046 columns), short and long queries around the
+    16-row blocks, empty sequences, local (16-bit key layout and 13-bit layout) / global / semi-local, free and priced end
+    gaps — against the oracle where it is fast enough, else against the tagged multi-wave kernel (itself pinned by the
+    reference goldens)."""
+    alpha, table = blosum62
+    lens = [(30, 510), (17, 511), (16, 512), (15, 513), (33, 1022), (2, 1023), (1, 1024), (48, 1025), (31, 1534), (32, 1535), (64, 1536),
+            (5, 2046), (0, 0), (0, 600), (700, 0), (2046, 2046), (1300, 700), (100, 90)]
+    pairs = [homolog_pair(80000 + n, max(q, t, 1)) for n, (q, t) in enumerate(lens)]
+    qs = [p[0][:q] for p, (q, t) in zip(pairs, lens)]
+    ts = [p[1][:t] for p, (q, t) in zip(pairs, lens)]
+    ctx = gpu_util.ctx()
+    for mode, gi, ge, h16 in ((3, 11, 1, 1), (3, 11, 1, 0), (3, 2, 0, 1), (1, 11, 1, 1), (4, 11, 1, 1), (0, 7, 2, 1), (2, 7, 2, 1)):
+        res = {}
+        for solo in (0, 1):
+            with ctx.hints(tag_solo=solo, h16=h16, key16=(0 if gi == 2 else 1)):
+                b = aln_amd.Batch(ctx, qs, ts)
+                b.dp_submatrix(alpha, table, mode, gi, ge, aln_amd.FWD, aln_amd.DP_FAST)
+                assert b.kernel_name().startswith("dp_affine_solo" if solo else "dp_affine_tag"), b.kernel_name()
+                b.reevaluate()
+                sc, lists, st = b.optimal()
+                res[solo] = ([b.get_cells(p) for p in range(len(qs))], sc, lists, st)
+                b.close()
+        a, c = res[0], res[1]
+        assert np.array_equal(a[3], c[3]) and np.array_equal(a[1].view(np.uint32), c[1].view(np.uint32)), (mode, gi)
+        for p in range(len(qs)):
+            for x, y in zip(a[0][p], c[0][p]):
+                assert np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32)), (mode, gi, h16, p, lens[p])
+            assert np.array_equal(a[2][p], c[2][p]), (mode, gi, p)
+        for p in (0, 3, 5, 7, 11, 13, 17):                    # narrow or short enough for the O(n^3) oracle
+            S = orc.sim_submatrix(qs[p], ts[p], alpha, table)
+            rc, D0, PQ0, PT0 = orc.dp_build(S, orc.Gap(mode, gi, ge))
+            D, PQ, PT = c[0][p]
+            assert np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (mode, gi, p)
+            assert np.array_equal(PQ, PQ0) and np.array_equal(PT, PT0), (mode, gi, p)

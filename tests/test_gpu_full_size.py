@@ -65,19 +65,20 @@ def check_opt(gold, score, pairs, what):
     assert np.asarray(pairs, np.int32).reshape(-1).tolist() == gold["opt"]["pairs"], what
 
 
-@pytest.mark.parametrize("kernel", ["tag", "tag_segq", "tag_nw1", "int"])
+@pytest.mark.parametrize("kernel", ["tag", "solo", "tag_segq", "tag_nw1", "int"])
 def test_c2_planes_and_optimal_equal_the_reference(kernel, blosum62):
     """Config 2: the 8 pinned pairs of the bench workload, local 11/1.  `tag` is the instantiation bench.py times
     (NW=2,R=2,X=8,local,h16,key16), one workgroup per pair; `tag_segq` the same instantiation with the segment queue bench.py's
     1024-pair launches use (every pair built by six workgroups that hand the row state on through HBM); `tag_nw1` a
-    one-wave-per-pair instantiation; `int` the untagged O(n^2) kernel."""
+    one-wave-per-pair instantiation; `solo` the one-wave-per-pair kernel that visits a pair's four 512-column strips in turn
+    (dp_affine_solo.hip); `int` the untagged O(n^2) kernel."""
     alpha, table = blosum62
     gold = doc()["c2"]["pairs"]
     qs, ts = zip(*[c2_pair(g["pair"]) for g in gold])
     for g, q, t in zip(gold, qs, ts):
         assert hashlib.sha256(q.encode()).hexdigest() == g["q_sha"] and hashlib.sha256(t.encode()).hexdigest() == g["t_sha"]
     ctx = gpu_util.ctx()
-    hints = {"tag": {"tag_segments": 0}, "tag_segq": {"tag_segments": -6},
+    hints = {"tag": {"tag_segments": 0}, "tag_segq": {"tag_segments": -6}, "solo": {"tag_solo": 1},
              "tag_nw1": {"dp_variant_nw": 1, "dp_variant_r": 4, "dp_variant_x": 8, "tag_segments": -6}, "int": {"tag_kernel": 0}}[kernel]
     with ctx.hints(**hints):
         b = aln_amd.Batch(ctx, list(qs), list(ts))
@@ -86,6 +87,9 @@ def test_c2_planes_and_optimal_equal_the_reference(kernel, blosum62):
     if kernel in ("tag", "tag_segq"):
         assert kn.startswith("dp_affine_tag") and "NW=2,R=2,X=8,local,h16,key16" in kn, kn
         assert kn.endswith("+segq") == (kernel == "tag_segq"), kn
+        assert b.plane_bytes_per_cell() == 4
+    elif kernel == "solo":
+        assert kn == "dp_affine_solo_kernel<local,h16,key16,occ3>", kn
         assert b.plane_bytes_per_cell() == 4
     elif kernel == "tag_nw1":
         assert "NW=1,R=4,X=8" in kn and kn.endswith("+segq"), kn
