@@ -87,9 +87,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
   const int lane_row4 = (lane & 31) * 4;
 
   // rows i0 .. i1 (1 <= i0, i1 <= Q-2) of strip S
-  auto phase = [&](auto S_, int i0, int i1) {
+  const int T_k = T, ld_k = ld, Q_k = Q, gi_k = gi, ge_k = ge, fd_k = prm.free_del, fi_k = prm.free_ins;
+  auto phase = [&](auto S_, int i0, int i1) __attribute__((always_inline)) {
     constexpr int S = decltype(S_)::value;
     asm volatile("" ::: "memory");            // the ring is written in one phase and read in the next: keep the accesses in program order
+    // Opaque copies of the wave-uniform inputs: everything derived from them (masks, plane descriptors, shifted gap constants)
+    // is then computed at the start of a phase — once per 16 rows — instead of being hoisted out of the row-block loop for all
+    // four strips at once, which costs more scalar registers than the wave has.
+    int T = T_k, ld = ld_k, Q = Q_k, gi = gi_k, ge = ge_k, free_del = fd_k, free_ins = fi_k;
+    asm volatile("" : "+s"(T), "+s"(ld), "+s"(Q), "+s"(gi), "+s"(ge), "+s"(free_del), "+s"(free_ins));
     int (&dk)[X] = dkS[S];
     int (&gmx)[X] = gmxS[S];
     int& cvk = cvkS[S];
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
     for (int x = 0; x < X; ++x) ak[x] = dk[x] + GK[x];
     uint32_t pf[X];
 
-    auto store_row = [&](int i) {
+    auto store_row = [&](int i) __attribute__((always_inline)) {
       const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(P + (size_t)i * ld, 0, ld * 2, 0x00020000);
       uint32_t pw[X / 2], hw[X / 2];
 #pragma unroll
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
     };
 
     // finish the row held in dk[]/pf[]: scan preparation for the next row, hand-over between the strips, find_max, store
-    auto finish_row = [&](int i, int dB, uint32_t pB) {
+    auto finish_row = [&](int i, int dB, uint32_t pB) __attribute__((always_inline)) {
 #pragma unroll
       for (int x = 0; x < X; ++x) ak[x] = dk[x] + GK[x];
       const int a0 = (lane == 0) ? NEGK : ak[0];            // column 0 is never a source; a later strip's first column is folded below
@@ -192,8 +198,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
       int dB = 0; uint32_t pB = kNullPtr;
       if (i == 1) {
         // row 1 (dpmatrix.h:409-418 / :579-590): match at (1,1), otherwise one deletion from the origin -> pointer (0,0)
-        auto row1 = [&](int c, int sK, int& dkv, uint32_t& pv) {
-          const int cost = (c >= 2 && !prm.free_del) ? ((gi + ge * (c - 2)) * (1 << KB)) : 0;
+        auto row1 = [&](int c, int sK, int& dkv, uint32_t& pv) __attribute__((always_inline)) {
+          const int cost = (c >= 2 && !free_del) ? ((gi + ge * (c - 2)) * (1 << KB)) : 0;
           int v = sK - cost;
           if (LOCAL) v = max(v, 0);
           const bool in = (unsigned)(c - 1) < (unsigned)(T - 2);
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
       // ---- interior rows (dpmatrix.h:447-486 / :607-649) ------------------------------------------------------------------
       const int FK = (gi + ge * (i - 2)) * (1 << KB);
       const int RK = ((ge * (i - 1)) * (1 << KB)) | P_INS | (TAGMAX - (i - 1));
-      const int colK = prm.free_ins ? 0 : FK;
+      const int colK = free_ins ? 0 : FK;
       int bk[X];
       {
         int pv = cvk;
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
   };
 
   const int nstrips = (ld + SW - 1) / SW;                      // strips that hold columns of this pair (the others would store nothing)
-  auto block = [&](int i0, int i1) {
+  auto block = [&](int i0, int i1) __attribute__((always_inline)) {
     phase(std::integral_constant<int, 0>(), i0, i1);
     if (nstrips > 1) phase(std::integral_constant<int, 1>(), i0, i1);
     if (nstrips > 2) phase(std::integral_constant<int, 2>(), i0, i1);
