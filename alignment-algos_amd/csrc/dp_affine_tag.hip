@@ -31,6 +31,15 @@
 
 namespace aln {
 
+__device__ __forceinline__ void setprio_dyn(int p) {     // s_setprio takes an immediate
+  switch (p & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+  }
+}
+
 // SEGQ: workgroups take (pair, row segment) items from the queue instead of building pair blockIdx.x from first to last row.
 template <int NW, int R, bool LOCAL, bool H16, int KBT, int X, bool SEGQ, int TB>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X == 16 ? 2 : 1, R * X == 16 ? 2 : 8))) void dp_affine_tag_kernel(
@@ -343,8 +352,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
     // 3.3 ms, and the SIMD idles behind the early finishers.  Alternating the user priority row by row (by the parity of
     // the wave's hardware slot) evens that out: -3...-6 % on a lone launch.  Launches that overlap on several streams
     // (bench.py) fill those gaps better and lose with it; launch_dp_affine_tag decides (one context alive -> on).
-    if (prm.alt_prio) {
-      if ((i ^ hwslot) & 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+    const int par = (i ^ hwslot) & 1;
+    if (prm.alt_prio & 0x100) {               // experiment: explicit levels, bits 0-1 / 4-5 = the row's bulk for even / odd parity
+      setprio_dyn(par ? (prm.alt_prio >> 4) & 3 : prm.alt_prio & 3);
+    } else if (prm.alt_prio == 1) {
+      if (par) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+    } else if (prm.alt_prio == 2) {           // experiment: the bulk of a row at low priority, its barrier-coupled end at high
+      __builtin_amdgcn_s_setprio(0);
+    } else if (prm.alt_prio == 3) {           // experiment: both
+      if (par) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
     }
     const int rowv = rowv_next;
     rowv_next = tab_at(code_n1 * 128, lane_row4);
@@ -425,6 +441,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
         }
       }
     }
+    if (prm.alt_prio & 0x100) setprio_dyn(par ? (prm.alt_prio >> 6) & 3 : (prm.alt_prio >> 2) & 3);   // bits 2-3 / 6-7 = the row's end
+    else if (prm.alt_prio == 2) __builtin_amdgcn_s_setprio(3);
+    else if (prm.alt_prio == 3) { if (par) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); }
     finish_row(i, dB, pB, sync, xin);
     }
     if (NW > 1 && !sync && (it & (lag - 1)) == lag - 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

@@ -94,6 +94,17 @@ class Gap:
         return C.byref(self.g)
 
 
+def deletion(gap, Q, T, q1, q2, t1, t2):
+    """Evaluator::deletion as the oracle evaluates it (aasubalib.h:27-51 / hmap2_eval.h:41-67 / gn2_eval.h:100-130)."""
+    err = C.c_int(0)
+    return np.float32(lib().orc_deletion(gap.ref, int(Q), int(T), int(q1), int(q2), int(t1), int(t2), C.byref(err)))
+
+
+def insertion(gap, Q, T, q1, q2, t1, t2):
+    err = C.c_int(0)
+    return np.float32(lib().orc_insertion(gap.ref, int(Q), int(T), int(q1), int(q2), int(t1), int(t2), C.byref(err)))
+
+
 def load_blosum(path):
     """Parse a BLOSUM-format file the way submatrix.cpp:16-54 does."""
     lines = open(path).read().split("\n")
