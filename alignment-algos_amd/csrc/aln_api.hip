@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <dlfcn.h>
+#include <thread>
 
 #include "aln_device.h"
 
@@ -172,7 +173,9 @@ void aln_batch_destroy(aln_batch* b) {
   if (!b) return;
   hipFree(b->d_pairs); hipFree(b->d_qcodes); hipFree(b->d_tcodes); hipFree(b->d_H); hipFree(b->d_P); hipFree(b->d_S);
   hipFree(b->d_res); hipFree(b->d_table32); hipFree(b->d_tablef); hipFree(b->d_tgi); hipFree(b->d_tge);
-  hipFree(b->d_path); hipFree(b->d_bounds); hipFree(b->d_xscratch); hipFree(b->d_tagq); hipFree(b->d_tagstate); hipFree(b->d_deltabR); hipFree(b->d_pair_deloff); hipFree(b->d_tcn); hipFree(b->d_deltab); hipFree(b->d_deltab_off); hipFree(b->d_instab);
+  hipFree(b->d_path); hipFree(b->d_bounds); hipFree(b->d_xscratch); hipFree(b->d_tagq); hipFree(b->d_tagstate); hipFree(b->d_deltabR); hipFree(b->d_pair_deloff);
+  if (b->h_path_pin) hipHostFree(b->h_path_pin);
+  if (b->h_res_pin) hipHostFree(b->h_res_pin); hipFree(b->d_tcn); hipFree(b->d_deltab); hipFree(b->d_deltab_off); hipFree(b->d_instab);
   for (int k = 0; k < 2; ++k) { if (b->h_slot[k]) hipHostFree(b->h_slot[k]); if (b->slot_ev[k]) hipEventDestroy(b->slot_ev[k]); }
   for (int k = 0; k < aln_batch::kEvRing; ++k) { if (b->ring0[k]) hipEventDestroy(b->ring0[k]); if (b->ring1[k]) hipEventDestroy(b->ring1[k]); }
   delete b;
@@ -651,40 +654,69 @@ int aln_batch_optimal_strings(aln_batch* b, float* scores, float* identity, int3
   if (!b || !tlines || !qlines || stride < 1) return ALN_E_ARG;
   if (!b->have_dp || b->have_sub) return ALN_E_STATE;
   if (b->n_pairs == 0) return ALN_OK;
+  aln_ctx* ctx = b->ctx;
   int rc = launch_traceback(b, false);
   if (rc) return rc;
   const int n = b->n_pairs;
-  std::vector<float> sc(n);
-  std::vector<int32_t> cnt(n), st(n), path((size_t)n * b->path_stride * 2);
-  rc = fetch_paths(b, sc.data(), cnt.data(), path.data(), b->path_stride, st.data(), !b->islocal, b->direction == ALN_FWD);
-  if (rc) return rc;
-  int worst = ALN_OK;
-  for (int p = 0; p < n; ++p) {
-    const PairDesc& d = b->h_pairs[p];
-    const char* q = b->q_res.data() + d.q_off;
-    const char* t = b->t_res.data() + d.t_off;
-    const int32_t* pl = path.data() + (size_t)p * b->path_stride * 2;
-    char* tl = tlines + (size_t)p * stride;
-    char* ql = qlines + (size_t)p * stride;
-    tl[0] = ql[0] = 0;
-    if (scores) scores[p] = sc[p];
-    if (status) status[p] = st[p];
-    if (lengths) lengths[p] = 0;
-    if (identity) identity[p] = 0.f;
-    if (st[p] != 0) { if (worst == ALN_OK) worst = st[p]; continue; }
-    aln_alignment a = {};
-    a.score = sc[p]; a.n_pairs = cnt[p]; a.pair_off = 0;
-    if (identity) identity[p] = aln_identity(q, d.Q, t, d.T, pl, cnt[p]);
-    // SequenceGaps needs a list that ends at the tail pair and never repeats a pair (Optimal_Rev's local lists can do both)
-    bool printable = cnt[p] > 0 && pl[2 * (cnt[p] - 1)] == d.Q - 1 && pl[2 * (cnt[p] - 1) + 1] == d.T - 1;
-    for (int k = 1; k < cnt[p] && printable; ++k) if (pl[2 * k] == pl[2 * k - 2] && pl[2 * k + 1] == pl[2 * k - 1]) printable = false;
-    if (!printable) continue;
-    const int len = aln_gapped_length(d.T, &a, 1, pl);
-    if (len >= stride) { worst = ALN_E_OVERFLOW; continue; }
-    const int rs = aln_gapped_strings(q, d.Q, t, d.T, &a, 1, pl, tl, ql, stride);
-    if (rs != ALN_OK) { if (worst == ALN_OK) worst = rs; continue; }
-    if (lengths) lengths[p] = len;
+  // results and pair lists come through pinned buffers the batch keeps (a pageable 16 MB destination costs more than the copy)
+  const size_t path_words = (size_t)n * b->path_stride * 2;
+  if (!b->h_path_pin) {
+    ALN_HIP_CHECK(ctx, hipHostMalloc((void**)&b->h_path_pin, path_words * 4));
+    ALN_HIP_CHECK(ctx, hipHostMalloc((void**)&b->h_res_pin, sizeof(PairResult) * n));
   }
+  ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->h_res_pin, b->d_res, sizeof(PairResult) * n, hipMemcpyDeviceToHost, ctx->stream));
+  ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->h_path_pin, b->d_path, path_words * 4, hipMemcpyDeviceToHost, ctx->stream));
+  ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  const PairResult* r = b->h_res_pin;
+  const bool corner_score = !b->islocal, flip = b->direction == ALN_FWD;
+  // the strings of different pairs are independent: a few host threads share the pairs
+  const int n_thr = std::max(1, std::min({(int)std::thread::hardware_concurrency(), 8, n / 64 + 1}));
+  std::vector<int> worst_of(n_thr, ALN_OK);
+  auto work = [&](int tid) {
+    std::vector<int32_t> pl;
+    for (int p = tid; p < n; p += n_thr) {
+      const PairDesc& d = b->h_pairs[p];
+      const char* q = b->q_res.data() + d.q_off;
+      const char* t = b->t_res.data() + d.t_off;
+      const int cnt = r[p].n_path;
+      const int32_t* src = b->h_path_pin + (size_t)p * b->path_stride * 2;
+      pl.resize((size_t)std::max(cnt, 1) * 2);
+      for (int k = 0; k < cnt; ++k) {                      // forward builds: device order is end -> start
+        const int sk = flip ? (cnt - 1 - k) : k;
+        pl[2 * k] = src[2 * sk]; pl[2 * k + 1] = src[2 * sk + 1];
+      }
+      char* tl = tlines + (size_t)p * stride;
+      char* ql = qlines + (size_t)p * stride;
+      tl[0] = ql[0] = 0;
+      const float sc = corner_score ? r[p].corner : r[p].best;
+      if (scores) scores[p] = sc;
+      if (status) status[p] = r[p].status;
+      if (lengths) lengths[p] = 0;
+      if (identity) identity[p] = 0.f;
+      int& worst = worst_of[tid];
+      if (r[p].status != 0) { if (worst == ALN_OK) worst = r[p].status; continue; }
+      aln_alignment a = {};
+      a.score = sc; a.n_pairs = cnt; a.pair_off = 0;
+      if (identity) identity[p] = aln_identity(q, d.Q, t, d.T, pl.data(), cnt);
+      // SequenceGaps needs a list that ends at the tail pair and never repeats a pair (Optimal_Rev's local lists can do both)
+      bool printable = cnt > 0 && pl[2 * (cnt - 1)] == d.Q - 1 && pl[2 * (cnt - 1) + 1] == d.T - 1;
+      for (int k = 1; k < cnt && printable; ++k) if (pl[2 * k] == pl[2 * k - 2] && pl[2 * k + 1] == pl[2 * k - 1]) printable = false;
+      if (!printable) continue;
+      const int len = aln_gapped_length(d.T, &a, 1, pl.data());
+      if (len >= stride) { worst = ALN_E_OVERFLOW; continue; }
+      const int rs = aln_gapped_strings(q, d.Q, t, d.T, &a, 1, pl.data(), tl, ql, stride);
+      if (rs != ALN_OK) { if (worst == ALN_OK) worst = rs; continue; }
+      if (lengths) lengths[p] = len;
+    }
+  };
+  if (n_thr == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (int k = 0; k < n_thr; ++k) th.emplace_back(work, k);
+    for (auto& x : th) x.join();
+  }
+  int worst = ALN_OK;
+  for (int w : worst_of) { if (w == ALN_E_OVERFLOW) worst = w; else if (w != ALN_OK && worst == ALN_OK) worst = w; }
   return worst;
 }
 

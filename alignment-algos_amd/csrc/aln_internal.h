@@ -142,6 +142,7 @@ struct aln_batch {
   hipEvent_t slot_ev[2] = {nullptr, nullptr};
   bool slot_local[2] = {false, false};
   int slot_head = 0, slot_count = 0;
+  int32_t* h_path_pin = nullptr; aln::PairResult* h_res_pin = nullptr;   // pinned readout buffers of aln_batch_optimal_strings
   std::vector<int32_t> h_bounds;
   // retained similarity description for reevaluate()
   std::vector<float> h_table; int32_t alpha_n; std::string alphabet;

@@ -1,4 +1,4 @@
-// dp_affine_tag.hip — tagged-key O(n^2) row-sweep DP for constant affine gaps, integer scores, Q,T <= 2048 (gfx950).
+// dp_affine_tag.hip — tagged-key O(n^2) row-sweep DP for constant affine gaps, integer scores, Q,T <= 4096 (gfx950).
 //
 // Same recurrence, mapping and tie-breaking as dp_affine_int.hip (reference dpmatrix.h:356-689 collapsed per
 // SURVEY.md A.6), rebuilt around what the gfx950 VALU actually issues at full rate.  Measured on MI355X
@@ -19,8 +19,9 @@
 // decoded by aln_device.h::decode_ptr).  Gap constants and the substitution table are pre-shifted by 13, so all
 // additions are plain full-rate adds that leave the tags alone.
 //
-// Per cell: ~18 VALU instructions (was ~63); the kernel is HBM-write bound.  The pointer word needs 13 bits, so the
-// plane is written as uint16 (0xFFFF = untouched): 6 bytes per cell reach HBM instead of the algorithmic 8.
+// Per cell: ~18 VALU instructions (was ~63).  The pointer word needs TB+2 <= 14 bits, so the pointer plane is written as uint16
+// (0xFFFF = untouched), and local builds write uint16 scores too: 4 bytes per cell reach HBM (6 with fp32 scores) instead of the
+// 8 of an fp32 + 32-bit layout.  What bounds the kernel, and what was tried on it: DESIGN.md 4.1.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>

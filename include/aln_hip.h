@@ -216,7 +216,8 @@ int aln_batch_reevaluate(aln_batch* b);
  * reference's refinement rounds — crcno.enumerate -> templ.updateCore -> dpm.reevaluate (gn2.cpp:146-185), where pre_calculate
  * derives new gap tables (gn2_eval.cpp:113-158) — for callers whose similarity does not change between rounds. */
 int aln_batch_set_gap(aln_batch* b, const aln_gap* gap);
-/* name of the DP kernel the last aln_batch_dp launched ("dp_affine_int<...>" / "dp_exact<...>") */
+/* name of the DP kernel the last aln_batch_dp / _reevaluate launched ("dp_affine_tag_kernel<NW=2,R=2,X=8,local,h16,key16>",
+ * "dp_affine_int_kernel<...>", "dp_exact_tiled_kernel<tpos,global,fwd>", "dp_exact_kernel<...>" ...) */
 const char* aln_batch_dp_kernel_name(const aln_batch* b);
 
 /* 7-argument DPMatrix ctor / build_subdpm (dpmatrix.h:169-189, :319-353) on one bounds rectangle per
