@@ -477,7 +477,7 @@ def test_edge_sizes(blosum62):
     for a, c in zip(planes["tag"][1], planes["exact"][1]):
         assert np.array_equal(np.asarray(a).view(np.uint32), np.asarray(c).view(np.uint32))
     assert np.array_equal(planes["tag"][2][1][0], planes["exact"][2][1][0])
-    # one residue more is beyond the tagged kernel: the int kernel takes over, same planes as the exact kernel
+    # one residue more needs 12 tag bits (pointer dialect 2, four waves of 1024 columns): same planes as the exact kernel
     q2, t2 = q + "A", t + "C"
     res = []
     for algo in (aln_amd.DP_FAST, aln_amd.DP_EXACT):
@@ -485,9 +485,27 @@ def test_edge_sizes(blosum62):
         b.dp_submatrix(alpha, table, 3, 11, 1, aln_amd.FWD, algo)
         res.append((b.kernel_name(), b.get_cells(0)))
         b.close()
-    assert "dp_affine_int" in res[0][0], res[0][0]
+    assert "dp_affine_tag" in res[0][0] and "tag12" in res[0][0], res[0][0]
     for a, c in zip(res[0][1], res[1][1]):
         assert np.array_equal(np.asarray(a).view(np.uint32), np.asarray(c).view(np.uint32))
+    # 4094 residues is the tagged kernel's largest matrix (4096 x 4096 with the sentinels); one more -> the int kernel, global too
+    q3, t3 = homolog_pair(77002, 4095)
+    for mode in (3, 1):
+        kn = []
+        cells = []
+        for qq, tt in ((q3[:4094], t3[:4094]), (q3, t3[:4000])):
+            b = aln_amd.Batch(gpu_util.ctx(), [qq], [tt])
+            b.dp_submatrix(alpha, table, mode, 11, 1, aln_amd.FWD, aln_amd.DP_FAST)
+            kn.append(b.kernel_name())
+            cells.append(b.get_cells(0))
+            b.close()
+        assert "tag12" in kn[0] and "dp_affine_int" in kn[1], kn
+        # the common part of the two matrices (same residues, same recurrence) is identical wherever no path can reach beyond it:
+        # row by row the first 4001 columns of the 4094-row build equal the int kernel's 4095-row build up to its last interior row
+        D0, PQ0, PT0 = cells[0]
+        D1, PQ1, PT1 = cells[1]
+        assert np.array_equal(D0[:4095, :4001].view(np.uint32), D1[:4095, :4001].view(np.uint32)), mode
+        assert np.array_equal(PQ0[:4095, :4001], PQ1[:4095, :4001]) and np.array_equal(PT0[:4095, :4001], PT1[:4095, :4001]), mode
 
 
 def tabulate_gaps(gap, Q, T):
