@@ -98,20 +98,20 @@ class GlooComm:
         import torch.distributed as dist
         if out is None:
             out = np.zeros(n_total, dtype=np.float32)
-        rec = np.zeros((n_max, 2), dtype=np.float32)
+        rec = np.zeros((n_max, 2), dtype=np.int32)                  # the C ABI's record: int32 index (-1 = padding), fp32 bits
         rec[:, 0] = -1
-        rec[:len(local_scores), 0] = np.asarray(global_index, dtype=np.float32)      # exact below 2^24 units
-        rec[:len(local_scores), 1] = np.asarray(local_scores, dtype=np.float32)
+        rec[:len(local_scores), 0] = np.asarray(global_index, dtype=np.int32)
+        rec[:len(local_scores), 1] = np.ascontiguousarray(local_scores, dtype=np.float32).view(np.int32)
         if self.world == 1:
             allr = rec[None]
         else:
             buf = torch.from_numpy(rec.reshape(-1))
-            got = torch.empty(self.world * buf.numel(), dtype=torch.float32)
+            got = torch.empty(self.world * buf.numel(), dtype=torch.int32)
             dist.all_gather_into_tensor(got, buf)
             allr = got.numpy().reshape(self.world, n_max, 2)
         for r in range(allr.shape[0]):
             m = allr[r, :, 0] >= 0
-            out[allr[r, m, 0].astype(np.int64)] = allr[r, m, 1]
+            out[allr[r, m, 0]] = np.ascontiguousarray(allr[r, m, 1]).view(np.float32)
         return out
 
     def close(self):

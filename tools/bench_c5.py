@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """BASELINE config 5: n x n synthetic proteins, length U[400,600] (seed 5000+s), local 11/1 BLOSUM62, scores only.
 
-One process per GPU (`python -m torch.distributed.run --nproc-per-node N tools/bench_c5.py n`): rank r owns the block of query
-rows aln_amd.shard.owned_range gives it, every rank holds all templates (2 MB), and the only collective is one all-gather of
-the fp32 score blocks (RCCL; 8 MiB per rank at n = 4096).  Without a launcher it runs the first `rows` query rows on one GPU.
+One process per GPU (`python -m torch.distributed.run --nproc-per-node N tools/bench_c5.py n`): rank r owns the query rows the C ABI's
+length-sorted deal (aln_deal_units) gives it, every rank holds all templates (2 MB), and the only collective is the C ABI's
+aln_gather_scores (one RCCL all-gather of (index, score) records; 16 MiB per rank at n = 4096 on 8 ranks).  Without a launcher it runs the first `rows` query rows on one GPU.
 Prints GCUPS = sum |q||t| / wall seconds of aln_score_all_vs_all (+ the gather), upload of the residues and download of the
 score block included.   usage: bench_c5.py [n] [rows]"""
 import os
@@ -15,7 +15,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "alignment-algos_amd"))
 import aln_amd  # noqa: E402
-from aln_amd.shard import owned_range  # noqa: E402
+from aln_amd.shard import Comm, GlooComm, deal_units, local_units  # noqa: E402
 from aln_amd.synth import MT19937, residues  # noqa: E402
 
 
@@ -50,31 +50,34 @@ def main():
         seqs.append(residues(g, ln))
     pool = aln_amd.SeqPool(seqs)
     ctx = aln_amd.Context(local_rank)
-    lo, hi = owned_range(rows, world, rank)
-    aln_amd.score_all_vs_all(ctx, pool, pool, alphabet, table, 11, 1, lo, min(lo + 64, hi))   # warm-up
+    lens = np.array([len(s) for s in seqs], dtype=np.int64)
+    if world > 1:
+        # query rows dealt by length (aln_deal_units), every rank holds all templates; ONE gather of (index, score) records
+        owner, slot = deal_units(lens[:rows], world)
+        mine = local_units(owner, slot, rank)
+        comm = GlooComm(world, rank) if rehearse else Comm(ctx, world, rank)
+        n_max = int(np.bincount(owner, minlength=world).max()) * n
+    else:
+        mine = np.arange(rows, dtype=np.int32)
+    qpool = pool if world == 1 else aln_amd.SeqPool([seqs[i] for i in mine])
+    aln_amd.score_all_vs_all(ctx, qpool, pool, alphabet, table, 11, 1, 0, min(64, len(mine)))   # warm-up
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    sc = aln_amd.score_all_vs_all(ctx, pool, pool, alphabet, table, 11, 1, lo, hi)
+    sc = aln_amd.score_all_vs_all(ctx, qpool, pool, alphabet, table, 11, 1, 0, len(mine))
     full = sc
     if world > 1:
-        import torch
-        mx = max(owned_range(rows, world, r)[1] - owned_range(rows, world, r)[0] for r in range(world))
-        buf = torch.zeros((mx, n), dtype=torch.float32, device=dev)
-        buf[:hi - lo] = torch.from_numpy(sc).to(dev)
-        out = torch.empty((world * mx, n), dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(out, buf)                       # the one collective of the path
-        out = out.cpu().numpy().reshape(world, mx, n)
-        full = np.concatenate([out[r, :owned_range(rows, world, r)[1] - owned_range(rows, world, r)[0]] for r in range(world)])
+        gidx = (mine.astype(np.int64)[:, None] * n + np.arange(n, dtype=np.int64)[None, :]).astype(np.int32).reshape(-1)
+        full = comm.gather(sc.reshape(-1), gidx, n_max, rows * n).reshape(rows, n)    # the one collective of the path
         dist.barrier()
     dt = time.perf_counter() - t0
     if rank == 0:
-        lens = np.array([len(s) for s in seqs], dtype=np.float64)
-        cells = lens[:rows].sum() * lens.sum()
+        cells = float(lens[:rows].sum()) * float(lens.sum())
         print("config5 %d x %d on %d rank(s)%s: %.3f s, %.1f GCUPS, checksum %.0f, self-scores ok=%s" % (
             rows, n, world, " [one-GPU rehearsal]" if rehearse else "", dt, cells / dt / 1e9, float(full.sum()),
             bool((np.diag(full[:, :rows]) >= full[:, :rows].max(axis=1) - 1e-6).all())))
     if world > 1:
+        comm.close()
         dist.destroy_process_group()
 
 
