@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
                                   : (((uint32_t)dk[r][x] >> KB) | (((uint32_t)dk[r][x + 1] >> KB) << 16));
         store_words(hw, rsH, vo16 + 2 * GW * r);
       } else if (inrange[r]) {
-        const float sc = 1.0f / 8192.0f;     // exact: values are multiples of 2^13
+        const float sc = 1.0f / (float)(1 << KB);     // exact: values are multiples of 2^KB
 #pragma unroll
         for (int x = 0; x < X; x += 4)
           *reinterpret_cast<float4*>(H + ro + GW * r + x) =
@@ -527,7 +527,8 @@ int tag_path_bits(const aln_batch* b, const float* table, int n, const aln_gap* 
     if (fabs((double)v) > maxs) maxs = fabs((double)v);
   }
   const double mn = (double)std::min(b->maxQ, b->maxT), mx = (double)std::max(b->maxQ, b->maxT);
-  if (b->maxQ <= 2048 && b->maxT <= 2048) return (maxs + ge) * ((double)b->maxQ + (double)b->maxT) + gi + maxs < 65536.0 ? 11 : 0;
+  if (b->maxQ <= 2048 && b->maxT <= 2048 && b->ctx->hints.tag_bits != 12)
+    return (maxs + ge) * ((double)b->maxQ + (double)b->maxT) + gi + maxs < 65536.0 ? 11 : 0;
   return (maxs * mn + 2 * gi + 3 * ge * mx + maxs < 100000.0 && gi + ge * mx < 16000.0) ? 12 : 0;
 }
 bool tag_path_legal(const aln_batch* b, const float* table, int n, const aln_gap* gap) { return tag_path_bits(b, table, n, gap) != 0; }

@@ -9,11 +9,12 @@
   c3    one 2000 x 2000 GLOBAL profile pair (bench_c3's generator, seeds 3000 / 4000) through oracle/_ref/ref_profile
         (real hmath.h / SimilarityMatrix / DPMatrix / Optimal): sha256 of S, H, PQ, PT + Optimal.
   long  four pairs between 2049 and 4094 residues (the kernels' paths beyond 2048 columns / rows): plane sha256 + Optimal.
+  longm four more such pairs in the non-local align_t (global, global-local, semi-local, mode 0).
   c5    a 32 x 32 block of config 5's sequence set (seed 5000+s, 400..600 aa): the score Optimal reports, local 11/1;
         and 12 x 12 blocks for the other four align_t.
 
 The O(n^3) reference needs ~25-40 s per 2000 x 2000 pair and core; everything runs once, in parallel, here.
-usage: gen_golden_full.py [c2] [c3] [c5] [long]   (default: all; parts not regenerated are kept from the existing file)
+usage: gen_golden_full.py [c2] [c3] [c5] [long] [longm]   (default: all; parts not regenerated are kept from the existing file)
 """
 import hashlib
 import json
@@ -192,7 +193,8 @@ def gen_c5(pool):
 
 def run_long(args):
     """One pair beyond 2048 residues (the tagged kernel's 12-bit tag layout, the int kernel, the exact kernel)."""
-    name, seed, qlen, tlen, homolog = args
+    name, seed, qlen, tlen, homolog = args[:5]
+    mode = args[5] if len(args) > 5 else 3
     if homolog:
         q, t = homolog_pair(seed, max(qlen, tlen))
         q, t = q[:qlen], t[:tlen]
@@ -200,14 +202,14 @@ def run_long(args):
         q, t = random_pair(seed, qlen, tlen)
     os.makedirs(TMP, exist_ok=True)
     path = os.path.join(TMP, "long_%s.bin" % name)
-    r = refrun.run_aa(q, t, 3, 11, 1, "fwd", ops=["bin", path, "opt"], timeout=7200)
+    r = refrun.run_aa(q, t, mode, 11, 1, "fwd", ops=["bin", path, "opt"], timeout=7200)
     raw = np.fromfile(path, dtype=np.int32)
     os.remove(path)
     Q, T = int(raw[0]), int(raw[1])
     planes = raw[2:].reshape(3, Q, T)
     opt = r["sets"]["OPT"]["alis"][0]
     print("long %s: %d x %d, opt score %g (%d pairs)" % (name, qlen, tlen, float(opt["score"]), len(opt["pairs"])), flush=True)
-    return {"name": name, "seed": seed, "qlen": qlen, "tlen": tlen, "homolog": bool(homolog), "mode": 3, "gi": 11, "ge": 1,
+    return {"name": name, "seed": seed, "qlen": qlen, "tlen": tlen, "homolog": bool(homolog), "mode": mode, "gi": 11, "ge": 1,
             "q_sha": hashlib.sha256(q.encode()).hexdigest(), "t_sha": hashlib.sha256(t.encode()).hexdigest(),
             "sha": {"H": sha(planes[0].view(np.uint32)), "PQ": sha(planes[1]), "PT": sha(planes[2])},
             "row_crc": {"H": row_crc(planes[0]), "P": row_crc(np.stack([planes[1], planes[2]], axis=2))},
@@ -217,12 +219,15 @@ def run_long(args):
 
 LONG_CASES = [("t2049", 2100, 1500, 2049, True), ("q2049", 2101, 2049, 700, True), ("sq3000", 2102, 3000, 3000, True),
               ("max4094", 2103, 4094, 4094, True)]
+# the same paths in the other align_t (fp32 score plane instead of uint16): global, global-local, semi-local
+LONGM_CASES = [("g2100", 2110, 2100, 2060, True, 1), ("gl2300", 2111, 2300, 2049, True, 2), ("sl2200", 2112, 2049, 2200, True, 4),
+               ("g3000r", 2113, 2500, 3000, False, 0)]
 
 
 def main():
     if not refrun.available():
         raise SystemExit("oracle/_ref/ref_harness missing: run `make -C oracle` where /root/reference exists")
-    parts = [a for a in sys.argv[1:] if a in ("c2", "c3", "c5", "long")] or ["c2", "c3", "c5", "long"]
+    parts = [a for a in sys.argv[1:] if a in ("c2", "c3", "c5", "long", "longm")] or ["c2", "c3", "c5", "long", "longm"]
     doc = {"generator": "oracle/gen_golden_full.py via oracle/_ref (real reference, g++ -O2, no -ffast-math)"}
     if os.path.exists(OUT):
         with open(OUT) as f:
@@ -230,6 +235,7 @@ def main():
     with ThreadPoolExecutor(8) as pool:
         fut3 = pool.submit(gen_c3) if "c3" in parts else None
         futl = [pool.submit(run_long, c) for c in LONG_CASES] if "long" in parts else []
+        futm = [pool.submit(run_long, c) for c in LONGM_CASES] if "longm" in parts else []
         if "c5" in parts:
             doc["c5"] = gen_c5(pool)
         if "c2" in parts:
@@ -239,6 +245,8 @@ def main():
         if futl:
             doc["long"] = {"note": "pairs beyond the 2048-residue limit of the 11-bit tag layout, local 11/1 BLOSUM62; homologs truncated to "
                                    "(qlen, tlen)", "pairs": [f.result() for f in futl]}
+        if futm:
+            doc["longm"] = {"note": "pairs beyond 2048 residues in the non-local align_t (mode field), 11/1 BLOSUM62", "pairs": [f.result() for f in futm]}
     with open(OUT, "w") as f:
         json.dump(doc, f, separators=(",", ":"))
     print("wrote", OUT, os.path.getsize(OUT), "bytes")

@@ -180,9 +180,12 @@ def test_error_behaviour(blosum62):
     b.close()
 
 
+@pytest.mark.parametrize("tag_bits", [0, 12])
 @pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
-def test_random_batch_vs_oracle(mode, blosum62):
-    """Ragged batch (lengths 1..520, crossing every wave/group boundary of the kernel variants) vs the oracle."""
+def test_random_batch_vs_oracle(mode, tag_bits, blosum62):
+    """Ragged batch (lengths 1..520, crossing every wave/group boundary of the kernel variants) vs the oracle; with the 11-bit
+    tag layout its lengths select, and with the 12-bit layout (pointer dialect 2, the instantiation of 2049..4094 residues)
+    forced by the `tag_bits` hint — every align_t, every score-plane type."""
     alpha, table = blosum62
     rng = np.random.RandomState(100 + mode)
     lens = [(1, 1), (2, 300), (300, 2), (254, 254), (255, 257), (256, 256), (510, 130), (130, 511), (260, 519)]
@@ -198,9 +201,10 @@ def test_random_batch_vs_oracle(mode, blosum62):
         qs.append(q)
         ts.append(t)
     for (gi, ge) in ((11, 1), (3, 0), (0, 2)):
-        b = aln_amd.Batch(gpu_util.ctx(), qs, ts)
-        b.dp_submatrix(alpha, table, mode, gi, ge, aln_amd.FWD, aln_amd.DP_FAST)
-        assert "dp_affine_tag" in b.kernel_name()
+        with gpu_util.ctx().hints(tag_bits=tag_bits):
+            b = aln_amd.Batch(gpu_util.ctx(), qs, ts)
+            b.dp_submatrix(alpha, table, mode, gi, ge, aln_amd.FWD, aln_amd.DP_FAST)
+        assert "dp_affine_tag" in b.kernel_name() and ("tag12" in b.kernel_name()) == (tag_bits == 12), b.kernel_name()
         scores, lists, status = b.optimal()
         for p, (q, t) in enumerate(zip(qs, ts)):
             S = orc.sim_submatrix(q, t, alpha, table)

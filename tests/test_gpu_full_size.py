@@ -282,3 +282,34 @@ def test_pairs_beyond_2048_residues_equal_the_reference(kernel, blosum62):
             assert bits(x["score"]) == bits(y["score"]) and np.array_equal(x["pairs"], y["pairs"])
         b2.close()
     b.close()
+
+
+@pytest.mark.parametrize("kernel", ["tag", "int", "exact"])
+def test_non_local_pairs_beyond_2048_residues_equal_the_reference(kernel, blosum62):
+    """The same three kernels in the other align_t (alib.h:20-26) beyond 2048 residues: fp32 score plane (scores leave the
+    uint16 range), end-gap rows/columns, tracebacks from the corner; one pair per align_t, each its own batch (a batch has
+    one align_t).  Against sha256 of the real reference's planes + its Optimal alignment."""
+    alpha, table = blosum62
+    d = doc()
+    if "longm" not in d:
+        pytest.skip("tests/golden/full_cases.json holds no 'longm' part")
+    ctx = gpu_util.ctx()
+    hints = {"tag": {}, "int": {"tag_kernel": 0}, "exact": {}}[kernel]
+    for g in d["longm"]["pairs"]:
+        q, t = long_pair(g)
+        assert hashlib.sha256(q.encode()).hexdigest() == g["q_sha"] and hashlib.sha256(t.encode()).hexdigest() == g["t_sha"]
+        with ctx.hints(**hints):
+            b = aln_amd.Batch(ctx, [q], [t])
+            b.dp_submatrix(alpha, table, g["mode"], g["gi"], g["ge"], aln_amd.FWD, aln_amd.DP_EXACT if kernel == "exact" else aln_amd.DP_FAST)
+        kn = b.kernel_name()
+        if kernel == "tag":
+            assert kn.startswith("dp_affine_tag") and "tag12" in kn, kn
+        elif kernel == "int":
+            assert kn.startswith("dp_affine_int"), kn
+        else:
+            assert "dp_exact_tiled" in kn, kn
+        scores, lists, status = b.optimal()
+        assert (status == 0).all()
+        check_planes(b, 0, g, "%s %s" % (kn, g["name"]))
+        check_opt(g, scores[0], lists[0], "%s %s" % (kn, g["name"]))
+        b.close()
