@@ -4,6 +4,8 @@
 
 namespace aln {
 
+constexpr int kTaskWords = 8;    // enumerate_par.hip: cell, slot, trie head, score, kind/force, (pad)
+constexpr int kParSerial = -100; // enumerate_par.hip -> host: this pair's set outgrows user_limit, search it with the one-wave kernel
 constexpr int kFrameWords = 8;   // q0, t0, k0, cursor, curr_head, curr_score, r, (pad) — one active branch() invocation
 
 struct EnumArgs {
@@ -22,6 +24,9 @@ struct EnumArgs {
   // batched launches (one block per pair): block b works on pair pair0 + b with the b-th slice of every pool
   int flags_stride;     // bytes between two pairs' flag rows (0: every pair shares one row)
   const int32_t* pair_list;   // block b works on pair pair_list[b] (nullptr: pair0 + b)
+  // enumerate_par.hip only
+  uint32_t* task;       // [ali_cap][kTaskWords]: pending sub-searches (every pending task owns a distinct slot)
+  uint32_t* slot_info;  // [ali_cap][3]: for slots the search created: parent slot, t0 of the branch node, candidate index
   // KSConstrainedNearOptimal only
   uint32_t k_limit;     // NOaliParams::k_limit: operations a branch node may keep
   int32_t* uid;         // uid of every alignment (kscw.h:121,262)

@@ -309,6 +309,10 @@ __global__ void enumerate_ks_kernel(const PairDesc* __restrict__ pairs, int pair
                                     const uint8_t* __restrict__ tcodes, const float* __restrict__ tgi, const float* __restrict__ tge,
                                     const float* __restrict__ Hbase, const uint32_t* __restrict__ Pbase,
                                     const float* __restrict__ Sbase, EnumArgs a);
+__global__ void enumerate_par_kernel(const PairDesc* __restrict__ pairs, int pair, EvalDev proto, const uint8_t* __restrict__ qcodes,
+                                     const uint8_t* __restrict__ tcodes, const float* __restrict__ tgi, const float* __restrict__ tge,
+                                     const float* __restrict__ Hbase, const uint32_t* __restrict__ Pbase,
+                                     const float* __restrict__ Sbase, EnumArgs a);
 __global__ void enumerate_cr_kernel(const PairDesc* __restrict__ pairs, int pair, EvalDev proto, const uint8_t* __restrict__ qcodes,
                                     const uint8_t* __restrict__ tcodes, const float* __restrict__ tgi, const float* __restrict__ tge,
                                     const float* __restrict__ Hbase, const uint32_t* __restrict__ Pbase,
@@ -342,6 +346,48 @@ bool set_cr_params(EnumArgs& a, const aln_noa* noa, int maxT) {
   return a.sort_limit >= 1 && a.sort_limit <= 512 && a.k_limit >= 1;
 }
 size_t cr_lds_bytes(const EnumArgs& a) { return (size_t)a.cand_cap * 8 + (size_t)a.sort_limit * 9 * 4; }
+
+// ---- the several-waves-per-pair search (enumerate_par.hip) -------------------------------------------------------------
+// LDS of one workgroup: flags + template codes + query codes (16-byte padded) + the 32 x 32 table
+size_t par_lds_bytes(int maxQ, int maxT) { return (size_t)((maxT + 15) & ~15) * 2 + (size_t)((maxQ + 15) & ~15) + 4096; }
+// waves per pair: context hint "enum_waves" (1 = the one-wave kernel, 2..16), else by how many pairs share the GPU; 0 = not usable
+int par_waves(const aln_batch* b, int kind, int n_pairs) {
+  if (kind != ALN_ENUM_CW && kind != ALN_ENUM_UCW) return 0;
+  const int h = b->ctx->hints.enum_waves;
+  if (h == 1 || par_lds_bytes(b->maxQ, b->maxT) > 60000 || b->maxQ > 65535 || b->maxT > 65535) return 0;
+  if (h >= 2) return std::min(h, 16);
+  return n_pairs >= 512 ? 4 : n_pairs >= 128 ? 8 : 16;
+}
+// The reference's set order from the slot tree enumerate_par_kernel recorded (see its header): pre-order, siblings by
+// (t0 of the branch node ascending, candidate index ascending).  info = 3 words per slot (parent, t0, candidate), valid for
+// slots > first; slots <= first keep their places.  old_of_new[k] = slot that holds the set's k-th alignment.
+void slot_order(int n_as, int first, const uint32_t* info, std::vector<int32_t>& old_of_new) {
+  old_of_new.resize(n_as);
+  for (int k = 0; k <= first && k < n_as; ++k) old_of_new[k] = k;
+  if (n_as <= first + 1) return;
+  const int m = n_as - first - 1;
+  std::vector<std::pair<uint64_t, int32_t>> ch(m);
+  for (int k = 0; k < m; ++k) {
+    const uint32_t* si = info + (size_t)(first + 1 + k) * 3;
+    ch[k].first = ((uint64_t)si[0] << 40) | ((uint64_t)(si[1] & 0xFFFFFu) << 20) | (uint64_t)(si[2] & 0xFFFFFu);
+    ch[k].second = first + 1 + k;
+  }
+  std::sort(ch.begin(), ch.end());
+  std::vector<int32_t> beg(n_as + 1, 0);                      // children of slot p: ch[beg[p] .. beg[p+1])
+  for (int k = 0; k < m; ++k) ++beg[(ch[k].first >> 40) + 1];
+  for (int p = 0; p < n_as; ++p) beg[p + 1] += beg[p];
+  std::vector<std::pair<int32_t, int32_t>> st;               // (slot, next child)
+  int counter = first;
+  old_of_new[counter++] = first;
+  st.emplace_back(first, beg[first]);
+  while (!st.empty()) {
+    auto& top = st.back();
+    if (top.second == beg[top.first + 1]) { st.pop_back(); continue; }
+    const int32_t c = ch[top.second++].second;
+    old_of_new[counter++] = c;
+    st.emplace_back(c, beg[c]);
+  }
+}
 }  // namespace
 
 extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* noa, const uint8_t* flags, aln_alignment* out,
@@ -389,7 +435,7 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   uint8_t* d_flags = nullptr; int32_t* d_out = nullptr;
   auto cleanup = [&]() {
     hipFree(a.node_pair); hipFree(a.node_next); hipFree(a.head); hipFree(a.score); hipFree(a.stack); hipFree(a.uid);
-    hipFree(a.cr_ali); hipFree(a.cr_reg);
+    hipFree(a.cr_ali); hipFree(a.cr_reg); hipFree(a.task); hipFree(a.slot_info);
     hipFree(d_flags); hipFree(d_out);
   };
 #define ETRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup(); return ALN_E_HIP; } } while (0)
@@ -399,6 +445,11 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   ETRY(hipMalloc((void**)&a.score, (size_t)a.ali_cap * 4));
   ETRY(hipMalloc((void**)&a.stack, (size_t)a.stack_cap * (ks ? 8 + 4 * a.k_limit : kFrameWords) * 4));
   if (ks) ETRY(hipMalloc((void**)&a.uid, (size_t)a.ali_cap * 4));
+  const int pw = par_waves(b, noa->kind, 1);         // cw / ucw: several waves search the pair (enumerate_par.hip)
+  if (pw) {
+    ETRY(hipMalloc((void**)&a.task, (size_t)a.ali_cap * kTaskWords * 4));
+    ETRY(hipMalloc((void**)&a.slot_info, (size_t)a.ali_cap * 12));
+  }
   if (cr) {
     ETRY(hipMalloc((void**)&a.cr_ali, (size_t)a.sort_limit * a.cr_tpad * 2));
     ETRY(hipMalloc((void**)&a.cr_reg, (size_t)a.cr_tpad * 4));
@@ -428,6 +479,10 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
     hipLaunchKernelGGL(enumerate_ks_kernel, dim3(1), dim3(64), (size_t)a.cand_cap * 8, ctx->stream, b->d_pairs, pair, proto,
                        sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr,
                        b->d_H, b->d_P, sub ? nullptr : b->d_S, a);
+  else if (pw)
+    hipLaunchKernelGGL(enumerate_par_kernel, dim3(1), dim3(64 * pw), par_lds_bytes(b->maxQ, b->maxT), ctx->stream, b->d_pairs, pair, proto,
+                       sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr,
+                       b->d_H, b->d_P, sub ? nullptr : b->d_S, a);
   else
   hipLaunchKernelGGL(enumerate_kernel, dim3(1), dim3(64), 0, ctx->stream, b->d_pairs, pair, proto, sub ? b->d_qcodes : nullptr,
                      sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr, b->d_H, b->d_P,
@@ -436,11 +491,32 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   int32_t hout[4] = {0, 0, 0, 0};
   ETRY(hipMemcpyAsync(hout, d_out, 12, hipMemcpyDeviceToHost, ctx->stream));
   ETRY(hipStreamSynchronize(ctx->stream));
+  bool used_par = pw != 0;
+  if (used_par && hout[2] == kParSerial) {            // the set outgrows user_limit: the serial order decides what is cut
+    used_par = false;
+    hipLaunchKernelGGL(enumerate_kernel, dim3(1), dim3(64), 0, ctx->stream, b->d_pairs, pair, proto, sub ? b->d_qcodes : nullptr,
+                       sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr, b->d_H, b->d_P,
+                       sub ? nullptr : b->d_S, a);
+    ETRY(hipGetLastError());
+    ETRY(hipMemcpyAsync(hout, d_out, 12, hipMemcpyDeviceToHost, ctx->stream));
+    ETRY(hipStreamSynchronize(ctx->stream));
+  }
   if (hout[2] != 0) { cleanup(); return hout[2]; }
   const int n_as = hout[0];
   std::vector<float> scores(n_as);
-  ETRY(hipMemcpyAsync(scores.data() + n_ex, a.score + n_ex, (size_t)(n_as - n_ex) * 4, hipMemcpyDeviceToHost, ctx->stream));
-  ETRY(hipStreamSynchronize(ctx->stream));
+  std::vector<int32_t> old_of_new;                    // set position -> slot (identity after the one-wave kernel)
+  if (used_par) {
+    std::vector<uint32_t> info((size_t)n_as * 3);
+    std::vector<float> raw(n_as);
+    ETRY(hipMemcpyAsync(info.data(), a.slot_info, info.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ETRY(hipMemcpyAsync(raw.data() + n_ex, a.score + n_ex, (size_t)(n_as - n_ex) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ETRY(hipStreamSynchronize(ctx->stream));
+    slot_order(n_as, n_ex, info.data(), old_of_new);
+    for (int k = n_ex; k < n_as; ++k) scores[k] = raw[old_of_new[k]];
+  } else {
+    ETRY(hipMemcpyAsync(scores.data() + n_ex, a.score + n_ex, (size_t)(n_as - n_ex) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ETRY(hipStreamSynchronize(ctx->stream));
+  }
   if (seed_opt) scores[0] = b->islocal ? res[pair].best : res[pair].corner;
   else for (int k = 0; k < n_ex; ++k) scores[k] = noa->existing_scores[k];
   std::vector<int32_t> uids;
@@ -461,7 +537,7 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
 
   // unroll the survivors on the device
   std::vector<int32_t> sel;
-  for (int k = 0; k < n_keep; ++k) if (keys[k].idx >= n_ex) sel.push_back(keys[k].idx);
+  for (int k = 0; k < n_keep; ++k) if (keys[k].idx >= n_ex) sel.push_back(used_par ? old_of_new[keys[k].idx] : keys[k].idx);
   const int stride = b->path_stride;
   std::vector<int32_t> lists((size_t)std::max<size_t>(sel.size(), 1) * stride * 2), lens(std::max<size_t>(sel.size(), 1));
   if (!sel.empty()) {
@@ -592,9 +668,10 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   int32_t *d_out = nullptr, *d_sel = nullptr, *d_lists = nullptr, *d_lens = nullptr, *d_list = nullptr;
   auto free_group = [&]() {
     hipFree(a.node_pair); hipFree(a.node_next); hipFree(a.head); hipFree(a.score); hipFree(a.stack); hipFree(a.uid);
-    hipFree(a.cr_ali); hipFree(a.cr_reg);
+    hipFree(a.cr_ali); hipFree(a.cr_reg); hipFree(a.task); hipFree(a.slot_info);
     hipFree(d_out); hipFree(d_sel); hipFree(d_lists); hipFree(d_lens); hipFree(d_list);
     a.node_pair = a.node_next = a.head = nullptr; a.score = nullptr; a.stack = nullptr; a.uid = nullptr; a.cr_ali = nullptr; a.cr_reg = nullptr;
+    a.task = a.slot_info = nullptr;
     d_out = d_sel = d_lists = d_lens = d_list = nullptr;
   };
   auto cleanup = [&]() {
@@ -633,104 +710,142 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   for (int p = 0; p < n; ++p) todo[p] = p;
   uint32_t node_cap = node_cap_per_pair ? node_cap_per_pair : (1u << 20);
   uint32_t ali_cap = ali_cap_per_pair ? ali_cap_per_pair : 65536u;
-  std::vector<int32_t> hout, sel, hlens, hlists;
-  std::vector<float> sc;
+  std::vector<int32_t> hout, sel, hlens, hlists, old_of_new;
+  std::vector<uint32_t> info;
+  std::vector<float> sc, raw;
   const int max_round = std::max(0, std::min(ctx->hints.enum_pool_retries, 3));
-  for (int round = 0; round <= max_round && !todo.empty(); ++round) {
-    std::vector<int32_t> again;
-    const size_t per_pair = (size_t)node_cap * 8 + (size_t)ali_cap * (ks ? 12 : 8) + (size_t)a0.stack_cap * frame_words * 4 +
-                            (pairs ? (size_t)K * pair_stride * 8 : 0) + (cr ? (size_t)a0.sort_limit * a0.cr_tpad * 2 + (size_t)a0.cr_tpad * 4 : 0);
-    size_t gmax = std::max<size_t>(1, kPoolBudget / per_pair);
-    if (round == 0) gmax = todo.size();                               // the caller sized round 0
-    for (size_t g0 = 0; g0 < todo.size(); g0 += gmax) {
-      const int gn = (int)std::min(gmax, todo.size() - g0);
-      const int32_t* ids = todo.data() + g0;
-      a = a0;
-      a.node_cap = node_cap; a.ali_cap = ali_cap;
-      BTRY(hipMalloc((void**)&a.node_pair, (size_t)gn * a.node_cap * 4));
-      BTRY(hipMalloc((void**)&a.node_next, (size_t)gn * a.node_cap * 4));
-      BTRY(hipMalloc((void**)&a.head, (size_t)gn * a.ali_cap * 4));
-      BTRY(hipMalloc((void**)&a.score, (size_t)gn * a.ali_cap * 4));
+  std::vector<int32_t> again, serial_todo;
+  // one group of pairs: search, sortSet, unroll.  use_par: the several-waves-per-pair kernel (cw / ucw); a pair whose set outgrows
+  // user_limit comes back as kParSerial and is searched again, with the same capacities, by the one-wave kernel.
+  auto run_group = [&](const int32_t* ids, int gn, bool last_round, int pw) -> int {
+    a = a0;
+    a.node_cap = node_cap; a.ali_cap = ali_cap;
+    BTRY(hipMalloc((void**)&a.node_pair, (size_t)gn * a.node_cap * 4));
+    BTRY(hipMalloc((void**)&a.node_next, (size_t)gn * a.node_cap * 4));
+    BTRY(hipMalloc((void**)&a.head, (size_t)gn * a.ali_cap * 4));
+    BTRY(hipMalloc((void**)&a.score, (size_t)gn * a.ali_cap * 4));
+    if (pw) {
+      BTRY(hipMalloc((void**)&a.task, (size_t)gn * a.ali_cap * kTaskWords * 4));
+      BTRY(hipMalloc((void**)&a.slot_info, (size_t)gn * a.ali_cap * 12));
+    } else {
       BTRY(hipMalloc((void**)&a.stack, (size_t)gn * a.stack_cap * frame_words * 4));
-      if (ks) BTRY(hipMalloc((void**)&a.uid, (size_t)gn * a.ali_cap * 4));
-      if (cr) {
-        BTRY(hipMalloc((void**)&a.cr_ali, (size_t)gn * a.sort_limit * a.cr_tpad * 2));
-        BTRY(hipMalloc((void**)&a.cr_reg, (size_t)gn * a.cr_tpad * 4));
-      }
-      BTRY(hipMalloc((void**)&d_out, (size_t)gn * 16));
-      BTRY(hipMalloc((void**)&d_list, (size_t)gn * 4));
-      BTRY(hipMemcpyAsync(d_list, ids, (size_t)gn * 4, hipMemcpyHostToDevice, ctx->stream));
-      a.flags = d_flags; a.out = d_out; a.pair_list = d_list;
-      BTRY(hipEventRecord(evs[0], ctx->stream));
-      if (cr)
-        hipLaunchKernelGGL(enumerate_cr_kernel, dim3(gn), dim3(64), cr_lds_bytes(a), ctx->stream, b->d_pairs, 0, proto,
-                           sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr,
-                           b->d_H, b->d_P, sub ? nullptr : b->d_S, a);
-      else if (ks)
-        hipLaunchKernelGGL(enumerate_ks_kernel, dim3(gn), dim3(64), (size_t)a.cand_cap * 8, ctx->stream, b->d_pairs, 0, proto,
-                           sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr,
-                           b->d_H, b->d_P, sub ? nullptr : b->d_S, a);
-      else
-        hipLaunchKernelGGL(enumerate_kernel, dim3(gn), dim3(64), 0, ctx->stream, b->d_pairs, 0, proto, sub ? b->d_qcodes : nullptr,
-                           sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr, b->d_H, b->d_P,
-                           sub ? nullptr : b->d_S, a);
-      BTRY(hipGetLastError());
-      BTRY(hipEventRecord(evs[1], ctx->stream));
-      hout.resize((size_t)gn * 4);
-      BTRY(hipMemcpyAsync(hout.data(), d_out, hout.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-      BTRY(hipStreamSynchronize(ctx->stream));
-      // per pair: sortSet on (score, index) keys, pick the survivors
-      sel.assign((size_t)gn * K, -1);
-      for (int g = 0; g < gn; ++g) {
-        const int p = ids[g];
-        for (int w = 0; w < 4; ++w) b->enum_usage[(size_t)p * 4 + w] = hout[4 * g + w];
-        status[p] = hout[4 * g + 2] ? hout[4 * g + 2] : res[p].status;
-        n_out[p] = 0;
-        if (status[p] == ALN_E_OVERFLOW && round < max_round &&
-            ((uint32_t)hout[4 * g + 1] >= a.node_cap - 64u || (uint32_t)hout[4 * g] >= a.ali_cap)) { again.push_back(p); continue; }
-        if (status[p] != 0) continue;
-        const int n_as = hout[4 * g];
-        sc.resize(n_as);
+    }
+    if (ks) BTRY(hipMalloc((void**)&a.uid, (size_t)gn * a.ali_cap * 4));
+    if (cr) {
+      BTRY(hipMalloc((void**)&a.cr_ali, (size_t)gn * a.sort_limit * a.cr_tpad * 2));
+      BTRY(hipMalloc((void**)&a.cr_reg, (size_t)gn * a.cr_tpad * 4));
+    }
+    BTRY(hipMalloc((void**)&d_out, (size_t)gn * 16));
+    BTRY(hipMalloc((void**)&d_list, (size_t)gn * 4));
+    BTRY(hipMemcpyAsync(d_list, ids, (size_t)gn * 4, hipMemcpyHostToDevice, ctx->stream));
+    a.flags = d_flags; a.out = d_out; a.pair_list = d_list;
+    BTRY(hipEventRecord(evs[0], ctx->stream));
+    if (cr)
+      hipLaunchKernelGGL(enumerate_cr_kernel, dim3(gn), dim3(64), cr_lds_bytes(a), ctx->stream, b->d_pairs, 0, proto,
+                         sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr,
+                         b->d_H, b->d_P, sub ? nullptr : b->d_S, a);
+    else if (ks)
+      hipLaunchKernelGGL(enumerate_ks_kernel, dim3(gn), dim3(64), (size_t)a.cand_cap * 8, ctx->stream, b->d_pairs, 0, proto,
+                         sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr,
+                         b->d_H, b->d_P, sub ? nullptr : b->d_S, a);
+    else if (pw)
+      hipLaunchKernelGGL(enumerate_par_kernel, dim3(gn), dim3(64 * pw), par_lds_bytes(b->maxQ, b->maxT), ctx->stream, b->d_pairs, 0, proto,
+                         sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr,
+                         b->d_H, b->d_P, sub ? nullptr : b->d_S, a);
+    else
+      hipLaunchKernelGGL(enumerate_kernel, dim3(gn), dim3(64), 0, ctx->stream, b->d_pairs, 0, proto, sub ? b->d_qcodes : nullptr,
+                         sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr, b->d_H, b->d_P,
+                         sub ? nullptr : b->d_S, a);
+    BTRY(hipGetLastError());
+    BTRY(hipEventRecord(evs[1], ctx->stream));
+    hout.resize((size_t)gn * 4);
+    BTRY(hipMemcpyAsync(hout.data(), d_out, hout.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    BTRY(hipStreamSynchronize(ctx->stream));
+    // per pair: sortSet on (score, index) keys, pick the survivors
+    sel.assign((size_t)gn * K, -1);
+    std::vector<char> deferred(gn, 0);
+    for (int g = 0; g < gn; ++g) {
+      const int p = ids[g];
+      for (int w = 0; w < 4; ++w) b->enum_usage[(size_t)p * 4 + w] = hout[4 * g + w];
+      status[p] = hout[4 * g + 2] ? hout[4 * g + 2] : res[p].status;
+      n_out[p] = 0;
+      if (status[p] == kParSerial) { status[p] = 0; serial_todo.push_back(p); deferred[g] = 1; continue; }
+      if (status[p] == ALN_E_OVERFLOW && !last_round &&
+          ((uint32_t)hout[4 * g + 1] >= a.node_cap - 64u || (uint32_t)hout[4 * g] >= a.ali_cap)) { again.push_back(p); deferred[g] = 1; continue; }
+      if (status[p] != 0) continue;
+      const int n_as = hout[4 * g];
+      sc.resize(n_as);
+      if (pw) {                                             // set order from the slot tree (enumerate_par.hip)
+        info.resize((size_t)n_as * 3); raw.resize(n_as);
+        BTRY(hipMemcpyAsync(info.data(), a.slot_info + (size_t)g * a.ali_cap * 3, info.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        BTRY(hipMemcpyAsync(raw.data() + 1, a.score + (size_t)g * a.ali_cap + 1, (size_t)(n_as - 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        BTRY(hipStreamSynchronize(ctx->stream));
+        slot_order(n_as, 1, info.data(), old_of_new);
+        for (int k = 1; k < n_as; ++k) sc[k] = raw[old_of_new[k]];
+      } else {
         BTRY(hipMemcpy(sc.data() + 1, a.score + (size_t)g * a.ali_cap + 1, (size_t)(n_as - 1) * 4, hipMemcpyDeviceToHost));
-        sc[0] = b->islocal ? res[p].best : res[p].corner;
-        std::vector<SortKey> keys(n_as);
-        for (int k = 0; k < n_as; ++k) { keys[k].score = sc[k]; keys[k].idx = k; }
-        const int mx = noa->number_suboptimal;
-        if (mx >= n_as) std::sort(keys.begin(), keys.end());
-        else if (mx > 0) { std::partial_sort(keys.begin(), keys.begin() + mx, keys.end()); keys.erase(keys.begin() + mx, keys.end()); }
-        int keep = (int)keys.size();
-        if (keep > K) { status[p] = ALN_E_OVERFLOW; keep = K; }     // the caller's K slots are too few for this set
-        n_out[p] = keep;
-        for (int k = 0; k < keep; ++k) { sel[(size_t)g * K + k] = keys[k].idx; scores[(size_t)p * K + k] = keys[k].score; }
       }
-      // unroll every survivor on the device
-      BTRY(hipMalloc((void**)&d_sel, sel.size() * 4));
-      BTRY(hipMalloc((void**)&d_lens, sel.size() * 4));
-      if (pairs) BTRY(hipMalloc((void**)&d_lists, sel.size() * (size_t)pair_stride * 8));
-      BTRY(hipMemcpyAsync(d_sel, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-      BTRY(hipEventRecord(evs[2], ctx->stream));
-      hipLaunchKernelGGL(enum_unroll_all_kernel, dim3(K, gn), dim3(64), 0, ctx->stream, a.node_pair, a.node_next, a.head, a.node_cap, a.ali_cap,
-                         d_sel, K, d_list, b->d_path, b->path_stride, b->d_res, d_lists, d_lens, pairs ? pair_stride : (1 << 30));
-      BTRY(hipGetLastError());
-      BTRY(hipEventRecord(evs[3], ctx->stream));
-      hlens.resize(sel.size());
-      BTRY(hipMemcpyAsync(hlens.data(), d_lens, sel.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-      if (pairs && gn == n && round == 0)      // the common case: everything in place, one copy
-        BTRY(hipMemcpyAsync(pairs, d_lists, sel.size() * (size_t)pair_stride * 8, hipMemcpyDeviceToHost, ctx->stream));
-      BTRY(hipStreamSynchronize(ctx->stream));
-      for (int g = 0; g < gn; ++g) {
-        const int p = ids[g];
-        if (std::find(again.begin(), again.end(), p) != again.end()) continue;
-        for (int k = 0; k < K; ++k) lengths[(size_t)p * K + k] = hlens[(size_t)g * K + k];
-        if (pairs && !(gn == n && round == 0))
-          BTRY(hipMemcpy(pairs + (size_t)p * K * pair_stride * 2, d_lists + (size_t)g * K * pair_stride * 2, (size_t)K * pair_stride * 8,
-                         hipMemcpyDeviceToHost));
+      sc[0] = b->islocal ? res[p].best : res[p].corner;
+      std::vector<SortKey> keys(n_as);
+      for (int k = 0; k < n_as; ++k) { keys[k].score = sc[k]; keys[k].idx = k; }
+      const int mx = noa->number_suboptimal;
+      if (mx >= n_as) std::sort(keys.begin(), keys.end());
+      else if (mx > 0) { std::partial_sort(keys.begin(), keys.begin() + mx, keys.end()); keys.erase(keys.begin() + mx, keys.end()); }
+      int keep = (int)keys.size();
+      if (keep > K) { status[p] = ALN_E_OVERFLOW; keep = K; }     // the caller's K slots are too few for this set
+      n_out[p] = keep;
+      for (int k = 0; k < keep; ++k) {
+        sel[(size_t)g * K + k] = pw ? old_of_new[keys[k].idx] : keys[k].idx;
+        scores[(size_t)p * K + k] = keys[k].score;
       }
-      float ms0 = 0.f, ms1 = 0.f;
-      BTRY(hipEventElapsedTime(&ms0, evs[0], evs[1]));
-      BTRY(hipEventElapsedTime(&ms1, evs[2], evs[3]));
-      b->enum_search_ms += ms0; b->enum_unroll_ms += ms1;
-      free_group();
+    }
+    // unroll every survivor on the device
+    BTRY(hipMalloc((void**)&d_sel, sel.size() * 4));
+    BTRY(hipMalloc((void**)&d_lens, sel.size() * 4));
+    if (pairs) BTRY(hipMalloc((void**)&d_lists, sel.size() * (size_t)pair_stride * 8));
+    BTRY(hipMemcpyAsync(d_sel, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    BTRY(hipEventRecord(evs[2], ctx->stream));
+    hipLaunchKernelGGL(enum_unroll_all_kernel, dim3(K, gn), dim3(64), 0, ctx->stream, a.node_pair, a.node_next, a.head, a.node_cap, a.ali_cap,
+                       d_sel, K, d_list, b->d_path, b->path_stride, b->d_res, d_lists, d_lens, pairs ? pair_stride : (1 << 30));
+    BTRY(hipGetLastError());
+    BTRY(hipEventRecord(evs[3], ctx->stream));
+    hlens.resize(sel.size());
+    BTRY(hipMemcpyAsync(hlens.data(), d_lens, sel.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    const bool in_place = pairs && gn == n;             // every pair of the batch, in batch order: one copy
+    if (in_place) BTRY(hipMemcpyAsync(pairs, d_lists, sel.size() * (size_t)pair_stride * 8, hipMemcpyDeviceToHost, ctx->stream));
+    BTRY(hipStreamSynchronize(ctx->stream));
+    for (int g = 0; g < gn; ++g) {
+      const int p = ids[g];
+      if (deferred[g]) continue;
+      for (int k = 0; k < K; ++k) lengths[(size_t)p * K + k] = hlens[(size_t)g * K + k];
+      if (pairs && !in_place)
+        BTRY(hipMemcpy(pairs + (size_t)p * K * pair_stride * 2, d_lists + (size_t)g * K * pair_stride * 2, (size_t)K * pair_stride * 8,
+                       hipMemcpyDeviceToHost));
+    }
+    float ms0 = 0.f, ms1 = 0.f;
+    BTRY(hipEventElapsedTime(&ms0, evs[0], evs[1]));
+    BTRY(hipEventElapsedTime(&ms1, evs[2], evs[3]));
+    b->enum_search_ms += ms0; b->enum_unroll_ms += ms1;
+    free_group();
+    return ALN_OK;
+  };
+  for (int round = 0; round <= max_round && !todo.empty(); ++round) {
+    again.clear(); serial_todo.clear();
+    for (int pass = 0; pass < 2; ++pass) {                // pass 1: the pairs pass 0's several-wave search handed back
+      const std::vector<int32_t>& list = pass == 0 ? todo : serial_todo;
+      if (list.empty()) continue;
+      const std::vector<int32_t> ids_all(list);          // (run_group appends to serial_todo)
+      const int pw0 = pass == 0 ? par_waves(b, noa->kind, (int)ids_all.size()) : 0;
+      const size_t per_pair = (size_t)node_cap * 8 + (size_t)ali_cap * (ks ? 12 : 8) +
+                              (pw0 ? (size_t)ali_cap * (kTaskWords * 4 + 12) : (size_t)a0.stack_cap * frame_words * 4) +
+                              (pairs ? (size_t)K * pair_stride * 8 : 0) + (cr ? (size_t)a0.sort_limit * a0.cr_tpad * 2 + (size_t)a0.cr_tpad * 4 : 0);
+      size_t gmax = std::max<size_t>(1, kPoolBudget / per_pair);
+      if (round == 0 && pass == 0) gmax = ids_all.size();               // the caller sized round 0
+      for (size_t g0 = 0; g0 < ids_all.size(); g0 += gmax) {
+        const int gn = (int)std::min(gmax, ids_all.size() - g0);
+        const int rcg = run_group(ids_all.data() + g0, gn, round == max_round, pw0 ? par_waves(b, noa->kind, gn) : 0);
+        if (rcg != ALN_OK) return rcg;
+      }
     }
     todo.swap(again);
     if (node_cap <= (1u << 29)) node_cap *= 4;

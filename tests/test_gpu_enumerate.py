@@ -14,12 +14,20 @@ from aln_amd.synth import homolog_pair
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[1, 0, 3], ids=["one_wave", "waves_auto", "waves3"])
+def enum_waves(request):
+    """cw / ucw searches run in the one-wave kernel (enumerate.hip) and in the several-waves-per-pair kernel (enumerate_par.hip:
+    tasks, slot tree, set order rebuilt on the host) — same sets, same order."""
+    with gpu_util.ctx().hints(enum_waves=request.param):
+        yield request.param
+
+
 def _flags(case):
     return np.array([int(ch) for ch in case["flags"]], dtype=np.uint8) if "flags" in case else np.ones(len(case["t"]) + 2, np.uint8)
 
 
 @pytest.mark.parametrize("prefix", ["known", "enum", "c1", "c4", "aaa"])
-def test_golden_enumeration(prefix, blosum62):
+def test_golden_enumeration(prefix, blosum62, enum_waves):
     alpha, table = blosum62
     n_sets = 0
     for case in goldens.cases(prefix):
@@ -43,9 +51,11 @@ def test_golden_enumeration(prefix, blosum62):
 
 
 @pytest.mark.parametrize("kind", ["cw", "ucw"])
-def test_enumeration_vs_oracle(kind, blosum62):
+def test_enumeration_vs_oracle(kind, blosum62, enum_waves):
     """Seeded mutated homologs, integer (fast DP kernel) and fractional (exact kernel) gaps, several thresholds, region
     counts and set limits; one resident batch, every pair enumerated from its own planes."""
+    if enum_waves == 3 and kind == "ucw":
+        pytest.skip("the unconstrained searches of this test run to user_limit (minutes): one several-wave variant is enough")
     alpha, table = blosum62
     rng = np.random.RandomState(17)
     lens = [9, 24, 57, 64, 90, 130]
@@ -80,7 +90,7 @@ def test_enumeration_vs_oracle(kind, blosum62):
             b.close()
 
 
-def test_enumeration_user_limit_and_overflow(blosum62):
+def test_enumeration_user_limit_and_overflow(blosum62, enum_waves):
     """user_limit forces the optimal path once the set is larger (cw.h:127-140); a too-small output buffer is an error."""
     alpha, table = blosum62
     q, t = homolog_pair(62001, 80, sub_rate=0.25, indel=3)
@@ -107,7 +117,7 @@ def test_enumeration_user_limit_and_overflow(blosum62):
 
 
 @pytest.mark.parametrize("kind", ["cw", "ucw"])
-def test_batched_enumeration_matches_oracle(kind, blosum62):
+def test_batched_enumeration_matches_oracle(kind, blosum62, enum_waves):
     """aln_batch_enumerate_all (BASELINE config 4 form): every pair of a ragged resident batch in ONE launch, per-pair
     SuboptFlags rows; set size, order, score bits and pair lists against the oracle, and against the one-pair entry."""
     alpha, table = blosum62
@@ -141,7 +151,7 @@ def test_batched_enumeration_matches_oracle(kind, blosum62):
         b.close()
 
 
-def test_batched_enumeration_overflow_is_per_pair(blosum62):
+def test_batched_enumeration_overflow_is_per_pair(blosum62, enum_waves):
     """A pool that is too small for one pair flags only that pair (status ALN_E_OVERFLOW); the others are complete."""
     alpha, table = blosum62
     pairs = [homolog_pair(64000, 12), homolog_pair(64001, 120, sub_rate=0.25, indel=3)]

@@ -135,8 +135,10 @@ def _check_cw_set(g, delta_key, q, t, n_out, scores, lengths, pairs, what):
         assert hashlib.sha256(qls[k].encode()).hexdigest() == r["qstr_sha"], "%s[%d] query line" % (what, k)
 
 
-def test_c4_enumerate_all_at_full_size(blosum62):
-    """Config 4 at its real size: a 64-pair 2000 x 2000 resident batch (config 2's build), ConstrainedNearOptimal with
+@pytest.mark.parametrize("waves", [0, 1], ids=["waves_auto", "one_wave"])
+def test_c4_enumerate_all_at_full_size(waves, blosum62):
+    """Both search kernels (enumerate_par.hip with the waves per pair the batch size selects; the one-wave enumerate.hip).
+    Config 4 at its real size: a 64-pair 2000 x 2000 resident batch (config 2's build), ConstrainedNearOptimal with
     NUM_SUBOPT=256 and 10 flag regions for every pair in ONE launch.  The 8 pinned pairs must equal the reference's sets
     (scores, pair lists, identities, gapped strings), the others the one-pair entry point aln_batch_enumerate."""
     alpha, table = blosum62
@@ -144,6 +146,7 @@ def test_c4_enumerate_all_at_full_size(blosum62):
     idx = list(range(56)) + [512, 513, 1022, 1023] + list(range(56, 60))
     pr = [c2_pair(p) for p in idx]
     ctx = gpu_util.ctx()
+    ctx.set_hint("enum_waves", waves)
     b = aln_amd.Batch(ctx, [p[0] for p in pr], [p[1] for p in pr])
     b.dp_submatrix(alpha, table, aln_amd.LOCAL, 11, 1, aln_amd.FWD, aln_amd.DP_FAST)
     assert "key16" in b.kernel_name()
@@ -182,6 +185,7 @@ def test_c4_enumerate_all_at_full_size(blosum62):
                 assert status[k] == 0
                 _check_cw_set(gold[p], "0.05", pr[k][0], pr[k][1], n_out[k], scores[k], lengths[k], pairs[k], "cw 0.05 pair %d" % p)
     b.close()
+    ctx.set_hint("enum_waves", 0)
 
 
 def test_c3_profile_pair_at_full_size():
