@@ -27,6 +27,9 @@ struct EnumArgs {
   // enumerate_par.hip only
   uint32_t* task;       // [ali_cap][kTaskWords]: pending sub-searches (every pending task owns a distinct slot)
   uint32_t* slot_info;  // [ali_cap][3]: for slots the search created: parent slot, t0 of the branch node, candidate index
+  const float* rowmax;  // [pairs of the batch][bm_rows][nbt] block maxima of the score plane (enum_blockmax_kernel), or nullptr
+  const float* colmax;  // [pairs of the batch][bm_cols][nbq]
+  int bm_rows, bm_cols, nbt, nbq, bm_pair0;   // (arrays start at pair bm_pair0 of the batch)
   // KSConstrainedNearOptimal only
   uint32_t k_limit;     // NOaliParams::k_limit: operations a branch node may keep
   int32_t* uid;         // uid of every alignment (kscw.h:121,262)
@@ -46,6 +49,16 @@ __device__ __forceinline__ uint32_t ld_u(const uint32_t* p) { return __hip_atomi
 __device__ __forceinline__ float ld_f(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_u(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_f(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Words that only the waves of ONE workgroup exchange (enumerate_par.hip's task stack): workgroup scope — on gfx950 an agent-scope
+// release (__threadfence) writes the XCD's L2 back, which a search that has megabytes of fresh trie nodes in it pays for every round.
+__device__ __forceinline__ uint32_t ld_w(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void st_w(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
+// sc + sv[lane 0] + sv[lane 1] + ... + sv[lane n-1], added in that order (fp32 is not associative; the reference adds one similarity
+// per path step).  n is wave-uniform: v_readlane_b32 with a scalar lane index, no LDS round trip per step.
+__device__ __forceinline__ float add_in_path_order(float sc, float sv, int n) {
+  for (int l = 0; l < n; ++l) sc += __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(sv), l));
+  return sc;
+}
 
 }  // namespace aln

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64) void enumerate_kernel(const PairDesc* __restric
         if (q - pq == 1) g = dev_deletion(e, pt, t);
         else g = dev_insertion(e, pq, q, pt, t);
       }
-      for (int l = 0; l < n_proc; ++l) sc += __shfl(sv, l);       // sc += sim (then sc -= 0 for a match step), in path order
+      sc = add_in_path_order(sc, sv, n_proc);       // sc += sim (then sc -= 0 for a match step), in path order
       if (gap_cell) {
         sc -= __shfl(g, F);
         q0 = __shfl(pq, F); t0 = __shfl(pt, F);
@@ -313,6 +313,9 @@ __global__ void enumerate_par_kernel(const PairDesc* __restrict__ pairs, int pai
                                      const uint8_t* __restrict__ tcodes, const float* __restrict__ tgi, const float* __restrict__ tge,
                                      const float* __restrict__ Hbase, const uint32_t* __restrict__ Pbase,
                                      const float* __restrict__ Sbase, EnumArgs a);
+__global__ void enum_blockmax_kernel(const PairDesc* __restrict__ pairs, const int32_t* __restrict__ pair_list, int pair0,
+                                     const float* __restrict__ Hbase, int h_mode, float* __restrict__ rowmax, float* __restrict__ colmax,
+                                     int bm_rows, int bm_cols, int nbt, int nbq, int bm_pair0);
 __global__ void enumerate_cr_kernel(const PairDesc* __restrict__ pairs, int pair, EvalDev proto, const uint8_t* __restrict__ qcodes,
                                     const uint8_t* __restrict__ tcodes, const float* __restrict__ tgi, const float* __restrict__ tge,
                                     const float* __restrict__ Hbase, const uint32_t* __restrict__ Pbase,
@@ -350,13 +353,34 @@ size_t cr_lds_bytes(const EnumArgs& a) { return (size_t)a.cand_cap * 8 + (size_t
 // ---- the several-waves-per-pair search (enumerate_par.hip) -------------------------------------------------------------
 // LDS of one workgroup: flags + template codes + query codes (16-byte padded) + the 32 x 32 table
 size_t par_lds_bytes(int maxQ, int maxT) { return (size_t)((maxT + 15) & ~15) * 2 + (size_t)((maxQ + 15) & ~15) + 4096; }
-// waves per pair: context hint "enum_waves" (1 = the one-wave kernel, 2..16), else by how many pairs share the GPU; 0 = not usable
+// waves per pair: context hint "enum_waves" (1 = the one-wave kernel, 2..16), else 16; 0 = not usable
 int par_waves(const aln_batch* b, int kind, int n_pairs) {
   if (kind != ALN_ENUM_CW && kind != ALN_ENUM_UCW) return 0;
   const int h = b->ctx->hints.enum_waves;
   if (h == 1 || par_lds_bytes(b->maxQ, b->maxT) > 60000 || b->maxQ > 65535 || b->maxT > 65535) return 0;
   if (h >= 2) return std::min(h, 16);
-  return n_pairs >= 512 ? 4 : n_pairs >= 128 ? 8 : 16;
+  (void)n_pairs;
+  return 16;                      // measured on 1024 config-4 pairs: 16 waves 0.33 s, 8 waves 0.48 s, 4 waves 0.75 s, one wave 4.6 s
+}
+// Block maxima of pairs [pair0, pair0 + np) for the pruned candidate scan (constant affine gaps, sequences up to 4096): fills
+// a.rowmax / a.colmax (caller frees) or leaves them null when the model does not qualify or the arrays would not pay.
+int make_blockmax(aln_batch* b, EnumArgs& a, int pair0, int np, float** d_row, float** d_col) {
+  *d_row = *d_col = nullptr;
+  if (b->gapdev.model != ALN_GAP_AFFINE_CONST || b->maxQ > 4096 || b->maxT > 4096 || !(b->gapdev.gi >= 0.f) || !(b->gapdev.ge >= 0.f)) return ALN_OK;
+  a.bm_rows = b->maxQ; a.bm_cols = b->maxT; a.nbt = (b->maxT + 63) / 64; a.nbq = (b->maxQ + 63) / 64; a.bm_pair0 = pair0;
+  const size_t nr = (size_t)np * a.bm_rows * a.nbt, nc = (size_t)np * a.bm_cols * a.nbq;
+  if ((nr + nc) * 4 > ((size_t)8 << 30)) return ALN_OK;
+  aln_ctx* ctx = b->ctx;
+  if (hipMalloc((void**)d_row, nr * 4) != hipSuccess || hipMalloc((void**)d_col, nc * 4) != hipSuccess) {
+    hipFree(*d_row); hipFree(*d_col); *d_row = *d_col = nullptr;
+    (void)hipGetLastError();
+    return ALN_OK;                                           // no memory for the shortcut: scan everything
+  }
+  hipLaunchKernelGGL(enum_blockmax_kernel, dim3(a.nbq, np), dim3(256), 0, ctx->stream, b->d_pairs, (const int32_t*)nullptr, pair0, b->d_H,
+                     b->h_mode, *d_row, *d_col, a.bm_rows, a.bm_cols, a.nbt, a.nbq, pair0);
+  ALN_HIP_CHECK(ctx, hipGetLastError());
+  a.rowmax = *d_row; a.colmax = *d_col;
+  return ALN_OK;
 }
 // The reference's set order from the slot tree enumerate_par_kernel recorded (see its header): pre-order, siblings by
 // (t0 of the branch node ascending, candidate index ascending).  info = 3 words per slot (parent, t0, candidate), valid for
@@ -436,6 +460,7 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   auto cleanup = [&]() {
     hipFree(a.node_pair); hipFree(a.node_next); hipFree(a.head); hipFree(a.score); hipFree(a.stack); hipFree(a.uid);
     hipFree(a.cr_ali); hipFree(a.cr_reg); hipFree(a.task); hipFree(a.slot_info);
+    hipFree((void*)a.rowmax); hipFree((void*)a.colmax);
     hipFree(d_flags); hipFree(d_out);
   };
 #define ETRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup(); return ALN_E_HIP; } } while (0)
@@ -448,6 +473,7 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   const int pw = par_waves(b, noa->kind, 1);         // cw / ucw: several waves search the pair (enumerate_par.hip)
   if (pw) {
     ETRY(hipMalloc((void**)&a.task, (size_t)a.ali_cap * kTaskWords * 4));
+    ETRY(hipMemsetAsync(a.task, 0, (size_t)a.ali_cap * kTaskWords * 4, ctx->stream));      // ready words: ticket + 1, never 0
     ETRY(hipMalloc((void**)&a.slot_info, (size_t)a.ali_cap * 12));
   }
   if (cr) {
@@ -462,6 +488,8 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   a.ptr_mode = b->ptr_mode;
   a.h_mode = b->h_mode;
   a.out = d_out;
+  float *d_bmr = nullptr, *d_bmc = nullptr;
+  if (pw) { int rcb = make_blockmax(b, a, pair, 1, &d_bmr, &d_bmc); if (rcb) { cleanup(); return rcb; } }
 
   EvalDev proto = {};
   proto.model = b->gapdev.model; proto.align_type = b->gapdev.align_type;
@@ -662,6 +690,7 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   const size_t frame_words = ks ? 8 + 4 * a0.k_limit : kFrameWords;
 
   uint8_t* d_flags = nullptr;
+  float *d_bmr = nullptr, *d_bmc = nullptr;
   hipEvent_t evs[4] = {nullptr, nullptr, nullptr, nullptr};
   // buffers of one group of pairs (see below)
   EnumArgs a = a0;
@@ -676,7 +705,7 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   };
   auto cleanup = [&]() {
     free_group();
-    hipFree(d_flags);
+    hipFree(d_flags); hipFree(d_bmr); hipFree(d_bmc);
     for (auto ev : evs) if (ev) hipEventDestroy(ev);
   };
 #define BTRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup(); return ALN_E_HIP; } } while (0)
@@ -698,6 +727,10 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   BTRY(hipStreamSynchronize(ctx->stream));
   b->enum_usage.assign((size_t)n * 4, 0);
   b->enum_search_ms = b->enum_unroll_ms = 0.f;
+  if (par_waves(b, noa->kind, n)) {                      // block maxima of every pair's score plane, once (the pruned scan of enumerate_par.hip)
+    int rcb = make_blockmax(b, a0, 0, n, &d_bmr, &d_bmc);
+    if (rcb) { cleanup(); return rcb; }
+  }
   for (int p = 0; p < n; ++p) { status[p] = 0; n_out[p] = 0; }
 
   // The search runs for GROUPS of pairs, one workgroup per pair, each with its own slice of the pools.  Round 0 is every pair
@@ -726,6 +759,7 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
     BTRY(hipMalloc((void**)&a.score, (size_t)gn * a.ali_cap * 4));
     if (pw) {
       BTRY(hipMalloc((void**)&a.task, (size_t)gn * a.ali_cap * kTaskWords * 4));
+      BTRY(hipMemsetAsync(a.task, 0, (size_t)gn * a.ali_cap * kTaskWords * 4, ctx->stream));   // ready words: ticket + 1, never 0
       BTRY(hipMalloc((void**)&a.slot_info, (size_t)gn * a.ali_cap * 12));
     } else {
       BTRY(hipMalloc((void**)&a.stack, (size_t)gn * a.stack_cap * frame_words * 4));
@@ -771,7 +805,7 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
       n_out[p] = 0;
       if (status[p] == kParSerial) { status[p] = 0; serial_todo.push_back(p); deferred[g] = 1; continue; }
       if (status[p] == ALN_E_OVERFLOW && !last_round &&
-          ((uint32_t)hout[4 * g + 1] >= a.node_cap - 64u || (uint32_t)hout[4 * g] >= a.ali_cap)) { again.push_back(p); deferred[g] = 1; continue; }
+          ((uint32_t)hout[4 * g + 1] >= a.node_cap - 64u || (uint32_t)hout[4 * g] + 64u >= a.ali_cap)) { again.push_back(p); deferred[g] = 1; continue; }
       if (status[p] != 0) continue;
       const int n_as = hout[4 * g];
       sc.resize(n_as);

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64) void enumerate_cr_kernel(const PairDesc* __rest
         if (q - pq == 1) g = dev_deletion(e, pt, t);
         else g = dev_insertion(e, pq, q, pt, t);
       }
-      for (int l = 0; l < n_proc; ++l) sc += __shfl(sv, l);      // score += sim, then -= 0 for a match step, in path order
+      sc = add_in_path_order(sc, sv, n_proc);      // score += sim, then -= 0 for a match step, in path order
       if (gap_cell) {
         sc -= __shfl(g, F);
         q0 = __shfl(pq, F); t0 = __shfl(pt, F);

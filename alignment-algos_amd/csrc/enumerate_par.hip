@@ -6,8 +6,9 @@
 // search tree itself is wide: every candidate a branch node accepts starts an independent sub-search (its own alignment, its
 // own score; the only shared state of the reference's recursion is the ORDER in which alignments are appended to the set).
 // This kernel therefore
-//   * turns every sub-search into a task (cell, alignment slot, trie head, score so far) on a per-pair stack in HBM,
-//   * lets the W waves of the pair's workgroup pop W tasks per round (three barriers a round),
+//   * turns every sub-search into a task (cell, alignment slot, trie head, score so far) in a per-pair ring in HBM,
+//   * lets the W waves of the pair's workgroup take tasks on their own (tickets handed out with LDS atomics, a ready word per
+//     record; no barrier inside the search),
 //   * scans a branch node ONCE, taking all accepted candidates of a 64-candidate group in parallel (the serial kernel resumes
 //     the scan after each accepted candidate's subtree), and
 //   * records for every new slot where the reference would have created it: (slot the branch node belongs to, template
@@ -18,8 +19,11 @@
 // The one thing that cannot be decided locally is "as.size() > user_limit" (cw.h:127 / ucw.h:110), which depends on how many
 // alignments exist at that moment of the serial order: if a pair's set outgrows user_limit, the kernel reports kParSerial and
 // the host repeats that pair with the one-wave kernel.
-// Sequence codes, the substitution table and the SuboptFlags row live in LDS; trie nodes, slots and tasks are handed out with
-// LDS atomics.  Results are bit-identical to enumerate_kernel's (tests run both against the reference's sets).
+// Termination: s_tail counts tickets handed out, s_done tasks finished (a task's pushes come before its s_done increment); a wave
+// that finds no ticket reads s_done, then s_tail: equal means that at the moment s_done was read nothing was pending or running.
+// Everything the waves exchange is workgroup scope (one CU): an agent-scope fence per step made this kernel 3 x slower (it writes
+// the XCD's L2 back).  Sequence codes, the substitution table and the SuboptFlags row live in LDS; trie nodes, slots and tickets
+// are handed out with LDS atomics.  Results are bit-identical to enumerate_kernel's (tests run both against the reference's sets).
 #include "enum_common.h"
 
 namespace aln {
@@ -30,8 +34,9 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
                                                             const float* __restrict__ Hbase, const uint32_t* __restrict__ Pbase,
                                                             const float* __restrict__ Sbase, EnumArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  __shared__ int s_top, s_status;
+  __shared__ int s_head, s_tail, s_done, s_status;
   __shared__ unsigned s_nodes, s_slots;
+  __shared__ uint16_t s_chunk[16][136];   // per wave: the blocks of a branch node's candidate row / column that can hold a passing candidate
   {
     const size_t bi = blockIdx.x;
     pair = a.pair_list ? a.pair_list[bi] : pair + (int)bi;
@@ -75,13 +80,16 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
   float thr = (1.f - a.delta_ratio) * top;       // cw.h:86-88
   { float alt = top - 0.1f; thr = (alt < thr) ? alt : thr; }
 
+  const uint32_t qcap = a.ali_cap;                    // ring of task records (every pending task owns a distinct slot, so <= ali_cap pend)
   if (threadIdx.x == 0) {
-    s_top = 1; s_status = 0; s_nodes = 0u; s_slots = (unsigned)a.first_slot + 1u;     // as.push_back(SingleAlignment())  cw.h:82 / ucw.h:78
+    s_head = 0; s_tail = 1; s_done = 0; s_status = 0; s_nodes = 0u; s_slots = (unsigned)a.first_slot + 1u;   // as.push_back(SingleAlignment())  cw.h:82 / ucw.h:78
     uint32_t* tk = a.task;                                                            // branch(final cell, seed slot)  cw.h:92 / ucw.h:86
-    st_u(tk + 0, ((uint32_t)(Q - 1) << 16) | (uint32_t)(T - 1)); st_u(tk + 1, (uint32_t)a.first_slot); st_u(tk + 2, kNoNode);
-    st_u(tk + 3, __float_as_uint(0.f)); st_u(tk + 4, 1u);
+    st_w(tk + 0, ((uint32_t)(Q - 1) << 16) | (uint32_t)(T - 1)); st_w(tk + 1, (uint32_t)a.first_slot); st_w(tk + 2, kNoNode);
+    st_w(tk + 3, __float_as_uint(0.f)); st_w(tk + 4, 1u);
+    __hip_atomic_store(tk + 5, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // ticket 0 is ready
     st_u(&a.head[a.first_slot], kNoNode); st_f(&a.score[a.first_slot], 0.f);
   }
+  __syncthreads();
 
   auto fail = [&](int code) { if (lane == 0) atomicCAS(&s_status, 0, code); };
   // n consecutive trie nodes for this wave; kNoNode: the pool is exhausted (status set)
@@ -93,23 +101,45 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
     return b;
   };
 
+  // Every wave takes tickets on its own: s_head = next ticket to take, s_tail = next ticket to hand out (a task's children are
+  // pushed by the wave that ran the task), s_done = tasks finished.  The search is over when every ticket handed out is done.
   for (;;) {
-    __threadfence();
-    __syncthreads();                                   // (A) the previous round's tasks, counters and status are complete
-    const int tp = s_top, st = s_status;
-    const int ntake = tp < W ? tp : W;
-    uint32_t tw0 = 0, tw1 = 0, tw2 = 0, tw3 = 0, tw4 = 0;
-    if (st == 0 && w < ntake) {                        // read the task before anybody may push over it
-      const uint32_t* tk = a.task + (size_t)(tp - 1 - w) * kTaskWords;
-      const uint32_t v = lane < 5 ? ld_u(tk + lane) : 0u;
+    int tkt = -1;
+    if (lane == 0) {
+      for (long spin = 0;; ++spin) {
+        if (__hip_atomic_load(&s_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) break;
+        const int d = __hip_atomic_load(&s_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);   // (read before s_tail: see header)
+        const int h = __hip_atomic_load(&s_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int t = __hip_atomic_load(&s_tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (h < t) {
+          int expect = h;
+          if (__hip_atomic_compare_exchange_strong(&s_head, &expect, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { tkt = h; break; }
+          continue;
+        }
+        if (d == t) break;                               // nothing pending, nothing running
+        if (spin > (1L << 22)) { atomicCAS(&s_status, 0, ALN_E_OVERFLOW); break; }   // (a wait of seconds: something is broken, end the search)
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    tkt = __shfl(tkt, 0);
+    if (tkt < 0) break;
+    uint32_t tw0, tw1, tw2, tw3, tw4;
+    {
+      const uint32_t* tk = a.task + (size_t)((uint32_t)tkt % qcap) * kTaskWords;
+      bool ready = false;
+      for (long spin = 0; spin < (1L << 22); ++spin) {    // the pusher writes the record after it took the ticket range
+        if (__hip_atomic_load(tk + 5, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == (uint32_t)tkt + 1u) { ready = true; break; }
+        if (__hip_atomic_load(&s_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!__shfl((int)ready, 0)) {                      // the search has failed elsewhere (or a record never came: broken): leave
+        if (lane == 0) atomicCAS(&s_status, 0, ALN_E_OVERFLOW);
+        break;
+      }
+      const uint32_t v = lane < 5 ? ld_w(tk + lane) : 0u;
       tw0 = (uint32_t)__shfl((int)v, 0); tw1 = (uint32_t)__shfl((int)v, 1); tw2 = (uint32_t)__shfl((int)v, 2);
       tw3 = (uint32_t)__shfl((int)v, 3); tw4 = (uint32_t)__shfl((int)v, 4);
     }
-    __syncthreads();                                   // (B) every wave has read tp, st and its task
-    if (st != 0 || tp == 0) break;
-    if (threadIdx.x == 0) s_top = tp - ntake;
-    __syncthreads();                                   // (C) pushes start above the remaining tasks
-    if (w >= ntake) continue;
 
     // ---- one task: opt_path / branch of ONE alignment slot until its branch node has spawned its children ---------------
     int q0 = (int)(tw0 >> 16), t0 = (int)(tw0 & 0xFFFFu);
@@ -118,6 +148,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
     float sc = __uint_as_float(tw3);
     bool is_branch = (tw4 & 1u) != 0, force = (tw4 & 2u) != 0;
     bool dead = false;
+    if (q0 < 1 || t0 < 1 || q0 >= Q || t0 >= T || slot >= a.ali_cap) { fail(ALN_E_OVERFLOW); break; }   // not a record of this search
 
     // as[slot].prepend(q0,t0); as[slot].prepend(0,0); score += H(q0,t0)   (cw.h:100-108 / ucw.h:93-101), then publish the slot
     auto base_case = [&]() {
@@ -165,7 +196,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
             if (q - pq == 1) g = dev_deletion(e, pt, t);
             else g = dev_insertion(e, pq, q, pt, t);
           }
-          for (int l = 0; l < n_proc; ++l) sc += __shfl(sv, l);            // path order: fp32 is not associative
+          sc = add_in_path_order(sc, sv, n_proc);            // path order: fp32 is not associative
           if (gap_cell) {
             sc -= __shfl(g, F);
             q0 = __shfl(pq, F); t0 = __shfl(pt, F);
@@ -189,13 +220,14 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
         const int nnew = n - (first ? 1 : 0);
         uint32_t bt = 0, bn = 0, bs = 0;
         if (lane == 0) {
-          bt = (uint32_t)atomicAdd(&s_top, n);
+          bt = (uint32_t)atomicAdd(&s_tail, n);
           bn = atomicAdd(&s_nodes, (unsigned)n);
           if (nnew) bs = atomicAdd(&s_slots, (unsigned)nnew);
         }
         bt = (uint32_t)__shfl((int)bt, 0); bn = (uint32_t)__shfl((int)bn, 0); bs = (uint32_t)__shfl((int)bs, 0);
         if (nnew && bs + (uint32_t)nnew > a.user_limit) { fail(kParSerial); dead = true; return; }   // the serial order decides what user_limit cuts
-        if (bt + (uint32_t)n > a.ali_cap || bn + (uint32_t)n > a.node_cap || bs + (uint32_t)nnew > a.ali_cap) {
+        const uint32_t pending = bt + (uint32_t)n - (uint32_t)__hip_atomic_load(&s_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (pending + 64u > qcap || bn + (uint32_t)n > a.node_cap || bs + (uint32_t)nnew > a.ali_cap) {
           fail(ALN_E_OVERFLOW); dead = true; return;
         }
         if ((m >> lane) & 1ull) {
@@ -210,19 +242,105 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
             uint32_t* si = a.slot_info + (size_t)sl * 3;
             si[0] = slot; si[1] = (uint32_t)t0; si[2] = (uint32_t)idx;
           }
-          uint32_t* tk = a.task + (size_t)(bt + (uint32_t)rnk) * kTaskWords;
-          st_u(tk + 0, ((uint32_t)cq << 16) | (uint32_t)ct); st_u(tk + 1, sl); st_u(tk + 2, nd);
-          st_u(tk + 3, __float_as_uint(r - g)); st_u(tk + 4, cw ? 0u : 1u);   // cw: opt_path(cand, k, false); ucw: branch(cand, k)
+          const uint32_t ticket = bt + (uint32_t)rnk;
+          uint32_t* tk = a.task + (size_t)(ticket % qcap) * kTaskWords;
+          st_w(tk + 0, ((uint32_t)cq << 16) | (uint32_t)ct); st_w(tk + 1, sl); st_w(tk + 2, nd);
+          st_w(tk + 3, __float_as_uint(r - g)); st_w(tk + 4, cw ? 0u : 1u);   // cw: opt_path(cand, k, false); ucw: branch(cand, k)
+          __hip_atomic_store(tk + 5, ticket + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         first = false;
       };
-      if (e.model == ALN_GAP_AFFINE_CONST) {
-        // as in enumerate.hip: 16 x 64 score loads in flight per trip; the accept masks of a trip are parked one per lane
-        constexpr int kTrip = 16;
-        const bool fdel = (e.align_type == ALN_LOCAL || e.align_type == ALN_SEMI_LOCAL || e.align_type == ALN_LOCAL_GLOBAL);
-        const bool fins = (e.align_type == ALN_LOCAL || e.align_type == ALN_SEMI_LOCAL || e.align_type == ALN_GLOBAL_LOCAL);
-        const uint16_t* H16p = reinterpret_cast<const uint16_t*>(Hbase) + pd.plane_off;
-        const float* H32p = Hbase + pd.plane_off;
+      const bool fdel = (e.align_type == ALN_LOCAL || e.align_type == ALN_SEMI_LOCAL || e.align_type == ALN_LOCAL_GLOBAL);
+      const bool fins = (e.align_type == ALN_LOCAL || e.align_type == ALN_SEMI_LOCAL || e.align_type == ALN_GLOBAL_LOCAL);
+      const uint16_t* H16p = reinterpret_cast<const uint16_t*>(Hbase) + pd.plane_off;
+      const float* H32p = Hbase + pd.plane_off;
+      if (e.model == ALN_GAP_AFFINE_CONST && a.rowmax && Q <= 4096 && T <= 4096 && e.gi >= 0.f && e.ge >= 0.f) {
+        // Pruned scan.  A candidate passes when fl(fl(H + r) - g) > thr; both roundings are monotone and, with gi, ge >= 0, g does
+        // not decrease with the gap's length.  So a 64-cell block of the candidate row / column can hold a passing candidate only
+        // if fl(fl(max H of the block + r) - g of its cell nearest to the node) > thr: one lane tests one block against the
+        // block maxima enum_blockmax_kernel prepared, and only the surviving blocks are read (for a near-optimal search: the one
+        // or two next to the node instead of all 31 + 31, and the column candidates are one 64-byte sector each).
+        const float* rmax = a.rowmax + ((size_t)(pair - a.bm_pair0) * a.bm_rows + (size_t)(q0 - 1)) * a.nbt;
+        const float* cmax = a.colmax + ((size_t)(pair - a.bm_pair0) * a.bm_cols + (size_t)(t0 - 1)) * a.nbq;
+        bool pass_d = false, pass_i = false;
+        {
+          const int lo = lane * 64 > 1 ? lane * 64 : 1;
+          int hi = lane * 64 + 63; hi = hi < t0 - 2 ? hi : t0 - 2;
+          if (lo <= hi) {
+            const int len = t0 - hi - 1;
+            const float g = (len < 1 || (fdel && t0 == T - 1)) ? 0.f : e.gi + e.ge * (float)(len - 1);
+            pass_d = (rmax[lane] + r) - g > thr;
+          }
+          int hq = lane * 64 + 63; hq = hq < q0 - 2 ? hq : q0 - 2;
+          if (lo <= hq) {
+            const int len = q0 - hq - 1;
+            const float g = (len < 1 || (fins && q0 == Q - 1)) ? 0.f : e.gi + e.ge * (float)(len - 1);
+            pass_i = (cmax[lane] + r) - g > thr;
+          }
+        }
+        const unsigned long long md = __ballot(pass_d), mi = __ballot(pass_i);
+        const int nd = __popcll(md), total = 1 + nd + __popcll(mi);
+        // chunk list in candidate order: the match, deletion blocks from t0-2 down, insertion blocks from q0-2 down
+        uint16_t* chunks = s_chunk[w];
+        if (lane == 0) chunks[0] = 0;
+        if (pass_d) chunks[1 + __popcll(lane < 63 ? md >> (lane + 1) : 0ull)] = (uint16_t)(0x100 | lane);
+        if (pass_i) chunks[1 + nd + __popcll(lane < 63 ? mi >> (lane + 1) : 0ull)] = (uint16_t)(0x200 | lane);
+        __builtin_amdgcn_wave_barrier();
+        // one candidate per lane and chunk; inside a block the lanes run against the index so that lane order = candidate order
+        auto cand = [&](int code, int& q, int& t, float& g, int& idx) -> bool {
+          const int kind = code >> 8, blk = code & 0xFF;
+          q = q0 - 1; t = t0 - 1; g = 0.f; idx = 0;
+          if (kind == 0) return lane == 0;
+          const int pos = blk * 64 + 63 - lane;
+          if (kind == 1) {                                      // aasubalib.h:27-51
+            const bool in = pos >= 1 && pos <= t0 - 2;
+            if (in) t = pos;
+            idx = t0 - 1 - t;
+            const int len = t0 - t - 1;
+            g = (len < 1 || (fdel && (t == 0 || t0 == T - 1))) ? 0.f : e.gi + e.ge * (float)(len - 1);
+            return in;
+          }
+          const bool in = pos >= 1 && pos <= q0 - 2;           // aasubalib.h:53-77
+          if (in) q = pos;
+          idx = ndel + 1 + (q0 - 2 - q);
+          const int len = q0 - q - 1;
+          g = (len < 1 || (fins && (q == 0 || q0 == Q - 1))) ? 0.f : e.gi + e.ge * (float)(len - 1);
+          return in;
+        };
+        constexpr int kTrip = 8;
+        for (int c0 = 0; c0 < total && !dead; c0 += kTrip) {
+          float fsc[kTrip];
+#pragma unroll
+          for (int u = 0; u < kTrip; ++u) {
+            const int code = c0 + u < total ? (int)chunks[c0 + u] : 0;
+            int q, t, idx; float g;
+            cand(code, q, t, g, idx);
+            fsc[u] = a.h_mode == 0 ? H32p[(size_t)q * ld + t] : (float)H16p[(size_t)q * ld + t];
+          }
+          unsigned long long mine = 0ull; bool any = false;
+#pragma unroll
+          for (int u = 0; u < kTrip; ++u) {
+            const int code = c0 + u < total ? (int)chunks[c0 + u] : 0;
+            int q, t, idx; float g;
+            const bool in = cand(code, q, t, g, idx) && c0 + u < total;
+            const bool ok = in && (idx == 0 ? fsc[u] + r > thr : fsc[u] + r - g > thr);
+            const unsigned long long m = __ballot(ok);
+            if (lane == u) mine = m;
+            any = any || m != 0ull;
+          }
+          if (!any) continue;
+          for (int u = 0; u < kTrip && !dead; ++u) {
+            const unsigned long long m = ((unsigned long long)(uint32_t)__shfl((int)(mine >> 32), u) << 32) | (uint32_t)__shfl((int)(mine & 0xFFFFFFFFull), u);
+            if (!m) continue;
+            int q, t, idx; float g;
+            cand((int)chunks[c0 + u], q, t, g, idx);
+            spawn(m, g, q, t, idx);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      } else if (e.model == ALN_GAP_AFFINE_CONST) {
+        // as in enumerate.hip, 8 x 64 score loads in flight per trip; the accept masks of a trip are parked one per lane
+        constexpr int kTrip = 8;
         auto cand = [&](int idx, int& q, int& t, float& g) {
           const bool isdel = idx <= ndel;                       // idx 0 (match) has the same row
           q = isdel ? q0 - 1 : q0 - 2 - (idx - ndel - 1);
@@ -294,11 +412,44 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
       if (dead || !first) break;                                            // children carry on (or the pools are exhausted)
       is_branch = false; force = true;                                      // nothing passed: finish along stored pointers, cw.h:196-203 / ucw.h:186-191
     }
+    if (lane == 0) __hip_atomic_fetch_add(&s_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // after this task's pushes
   }
+  __syncthreads();
   if (threadIdx.x == 0) {
     const int status = s_status;
     a.out[0] = (int32_t)s_slots; a.out[1] = (int32_t)s_nodes; a.out[2] = status;
   }
+}
+
+
+// Block maxima of the score plane for the pruned scan above: colmax[t][bq] = max of H over rows 64 bq .. 64 bq + 63 of column t,
+// rowmax[q][bt] = max over columns 64 bt .. 64 bt + 63 of row q.  grid (row tiles, pairs), 256 threads; every cell is read twice
+// (the second time from L2): ~3 ms for 1024 pairs of 2002 x 2002.
+__global__ __launch_bounds__(256) void enum_blockmax_kernel(const PairDesc* __restrict__ pairs, const int32_t* __restrict__ pair_list, int pair0,
+                                                           const float* __restrict__ Hbase, int h_mode, float* __restrict__ rowmax,
+                                                           float* __restrict__ colmax, int bm_rows, int bm_cols, int nbt, int nbq, int bm_pair0) {
+  const int pair = pair_list ? pair_list[blockIdx.y] : pair0 + (int)blockIdx.y;
+  const PairDesc pd = pairs[pair];
+  const int Q = pd.Q, T = pd.T, ld = pd.ld, bq = blockIdx.x;
+  const int qa = bq * 64, qb = qa + 64 < Q ? qa + 64 : Q;
+  if (qa >= Q) return;
+  const float NEG = -3.0e38f;
+  float* cm = colmax + (size_t)(pair - bm_pair0) * bm_cols * nbq;
+  float* rm = rowmax + (size_t)(pair - bm_pair0) * bm_rows * nbt;
+  for (int t = threadIdx.x; t < T; t += 256) {
+    float m = NEG;
+    for (int q = qa; q < qb; ++q) m = fmaxf(m, load_score(Hbase, pd.plane_off, ld, q, t, h_mode));
+    cm[(size_t)t * nbq + bq] = m;
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int q = qa + w; q < qb; q += 4)
+    for (int bt = 0; bt * 64 < T; ++bt) {
+      const int t = bt * 64 + lane;
+      float m = t < T ? load_score(Hbase, pd.plane_off, ld, q, t, h_mode) : NEG;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      if (lane == 0) rm[(size_t)q * nbt + bt] = m;
+    }
 }
 
 }  // namespace aln

@@ -190,7 +190,7 @@ int aln_has_gfx950(void);
  *   "dp_variant_nw" "dp_variant_r" "dp_variant_x"   force a row-sweep instantiation (0 = automatic)
  *   "exact_tiles" "exact_literal" "exact_alt_prio" "score_packed" "enum_node_cap" "tag_lag"
  *   "enum_waves"                    ConstrainedNearOptimal / UnconstrainedNearOptimal search: waves per pair (2..16, enumerate_par.hip);
- *                                   1 = the one-wave kernel; 0 (default) = 4 / 8 / 16 by the number of pairs.  Same sets, same order.
+ *                                   1 = the one-wave kernel; 0 (default) = 16.  Same sets, same order.
  *   "enum_pool_retries"             aln_batch_enumerate_all: how often a pair whose pools overflowed is searched again with four
  *                                   times the capacity (default 2)
  * Unknown key -> ALN_E_ARG.  No hint changes any result. */
