@@ -36,6 +36,7 @@ const HintDef kDefs[] = {
     {"score_packed", "ALN_SCORE_NO_PACKED", true, &aln_hints::score_packed},
     {"enum_pool_retries", "ALN_ENUM_POOL_RETRIES", false, &aln_hints::enum_pool_retries},
     {"enum_waves", "ALN_ENUM_WAVES", false, &aln_hints::enum_waves},
+    {"enum_debug", "ALN_ENUM_DEBUG", false, &aln_hints::enum_debug},
     {"plane_row_align", "ALN_PLANE_ROW_ALIGN", false, &aln_hints::plane_row_align},
 };
 

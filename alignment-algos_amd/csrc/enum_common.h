@@ -4,6 +4,7 @@
 
 namespace aln {
 
+constexpr uint32_t kChunkNodes = 1u << 16;   // enumerate_par.hip: trie nodes a workgroup takes from the launch's pool at a time
 constexpr int kTaskWords = 8;    // enumerate_par.hip: cell, slot, trie head, score, kind/force, (pad)
 constexpr int kParSerial = -100; // enumerate_par.hip -> host: this pair's set outgrows user_limit, search it with the one-wave kernel
 constexpr int kFrameWords = 8;   // q0, t0, k0, cursor, curr_head, curr_score, r, (pad) — one active branch() invocation
@@ -27,6 +28,11 @@ struct EnumArgs {
   // enumerate_par.hip only
   uint32_t* task;       // [ali_cap][kTaskWords]: pending sub-searches (every pending task owns a distinct slot)
   uint32_t* slot_info;  // [ali_cap][3]: for slots the search created: parent slot, t0 of the branch node, candidate index
+  // node pools shared by the pairs of a launch (32-bit node indices: < 2^32 nodes each; workgroup i uses pool i % n_pools),
+  // handed out in chunks of kChunkNodes
+  uint32_t* chunk_next; // [n_pools] next free chunk (device counters)
+  uint32_t n_chunks;    // chunks per pool
+  uint32_t n_pools;
   const float* rowmax;  // [pairs of the batch][bm_rows][nbt] block maxima of the score plane (enum_blockmax_kernel), or nullptr
   const float* colmax;  // [pairs of the batch][bm_cols][nbq]
   int bm_rows, bm_cols, nbt, nbq, bm_pair0;   // (arrays start at pair bm_pair0 of the batch)

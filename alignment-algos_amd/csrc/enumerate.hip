@@ -324,6 +324,7 @@ __global__ void enumerate_cr_kernel(const PairDesc* __restrict__ pairs, int pair
 
 // ---------------------------------------------------------------------------------------------------------
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -454,12 +455,14 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   a.ali_cap = user_limit + 65536u + (uint32_t)n_ex;
   a.node_cap = 48u << 20;
   if (ctx->hints.enum_node_cap > 0) a.node_cap = (uint32_t)ctx->hints.enum_node_cap;
+  const int pw = par_waves(b, noa->kind, 1);         // cw / ucw: several waves search the pair (enumerate_par.hip)
+  if (pw) a.node_cap = std::max(a.node_cap, kChunkNodes) / kChunkNodes * kChunkNodes;   // its node pool comes in chunks
   a.stack_cap = (uint32_t)(d.Q + d.T + 8);
   if (cr && !set_cr_params(a, noa, d.T)) return ALN_E_ARG;
   uint8_t* d_flags = nullptr; int32_t* d_out = nullptr;
   auto cleanup = [&]() {
     hipFree(a.node_pair); hipFree(a.node_next); hipFree(a.head); hipFree(a.score); hipFree(a.stack); hipFree(a.uid);
-    hipFree(a.cr_ali); hipFree(a.cr_reg); hipFree(a.task); hipFree(a.slot_info);
+    hipFree(a.cr_ali); hipFree(a.cr_reg); hipFree(a.task); hipFree(a.slot_info); hipFree(a.chunk_next);
     hipFree((void*)a.rowmax); hipFree((void*)a.colmax);
     hipFree(d_flags); hipFree(d_out);
   };
@@ -470,11 +473,14 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   ETRY(hipMalloc((void**)&a.score, (size_t)a.ali_cap * 4));
   ETRY(hipMalloc((void**)&a.stack, (size_t)a.stack_cap * (ks ? 8 + 4 * a.k_limit : kFrameWords) * 4));
   if (ks) ETRY(hipMalloc((void**)&a.uid, (size_t)a.ali_cap * 4));
-  const int pw = par_waves(b, noa->kind, 1);         // cw / ucw: several waves search the pair (enumerate_par.hip)
   if (pw) {
     ETRY(hipMalloc((void**)&a.task, (size_t)a.ali_cap * kTaskWords * 4));
     ETRY(hipMemsetAsync(a.task, 0, (size_t)a.ali_cap * kTaskWords * 4, ctx->stream));      // ready words: ticket + 1, never 0
     ETRY(hipMalloc((void**)&a.slot_info, (size_t)a.ali_cap * 12));
+    a.n_chunks = a.node_cap / kChunkNodes;              // (node_cap was rounded to chunks above)
+    a.n_pools = 1;
+    ETRY(hipMalloc((void**)&a.chunk_next, 4));
+    ETRY(hipMemsetAsync(a.chunk_next, 0, 4, ctx->stream));
   }
   if (cr) {
     ETRY(hipMalloc((void**)&a.cr_ali, (size_t)a.sort_limit * a.cr_tpad * 2));
@@ -629,7 +635,7 @@ namespace aln {
 // one wave per (pair, slot): slot's alignment index comes from sel[]; -1 = empty, 0 = the pair's Optimal alignment
 // (taken from the traceback list, which is stored end -> start), otherwise a trie walk.
 __global__ __launch_bounds__(64) void enum_unroll_all_kernel(const uint32_t* __restrict__ node_pair, const uint32_t* __restrict__ node_next,
-                                                             const uint32_t* __restrict__ head, uint32_t node_cap, uint32_t ali_cap,
+                                                             const uint32_t* __restrict__ head, size_t node_stride, int n_pools, uint32_t ali_cap,
                                                              const int32_t* __restrict__ sel, int K, const int32_t* __restrict__ pair_list,
                                                              const int32_t* __restrict__ path,
                                                              int path_stride, const PairResult* __restrict__ res,
@@ -648,8 +654,10 @@ __global__ __launch_bounds__(64) void enum_unroll_all_kernel(const uint32_t* __r
     return;
   }
   if (threadIdx.x != 0) return;
-  const uint32_t* np_ = node_pair + (size_t)p * node_cap;
-  const uint32_t* nn_ = node_next + (size_t)p * node_cap;
+  // a slice per pair (one-wave kernels: n_pools = 0) or the pool workgroup p of enumerate_par.hip used (p % n_pools)
+  const size_t nbase = n_pools ? (size_t)(p % n_pools) * node_stride : (size_t)p * node_stride;
+  const uint32_t* np_ = node_pair + nbase;
+  const uint32_t* nn_ = node_next + nbase;
   uint32_t node = head[(size_t)p * ali_cap + idx];
   int n = 0;
   while (node != kNoNode && n < stride) {
@@ -697,10 +705,10 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   int32_t *d_out = nullptr, *d_sel = nullptr, *d_lists = nullptr, *d_lens = nullptr, *d_list = nullptr;
   auto free_group = [&]() {
     hipFree(a.node_pair); hipFree(a.node_next); hipFree(a.head); hipFree(a.score); hipFree(a.stack); hipFree(a.uid);
-    hipFree(a.cr_ali); hipFree(a.cr_reg); hipFree(a.task); hipFree(a.slot_info);
+    hipFree(a.cr_ali); hipFree(a.cr_reg); hipFree(a.task); hipFree(a.slot_info); hipFree(a.chunk_next);
     hipFree(d_out); hipFree(d_sel); hipFree(d_lists); hipFree(d_lens); hipFree(d_list);
     a.node_pair = a.node_next = a.head = nullptr; a.score = nullptr; a.stack = nullptr; a.uid = nullptr; a.cr_ali = nullptr; a.cr_reg = nullptr;
-    a.task = a.slot_info = nullptr;
+    a.task = a.slot_info = a.chunk_next = nullptr;
     d_out = d_sel = d_lists = d_lens = d_list = nullptr;
   };
   auto cleanup = [&]() {
@@ -753,8 +761,18 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   auto run_group = [&](const int32_t* ids, int gn, bool last_round, int pw) -> int {
     a = a0;
     a.node_cap = node_cap; a.ali_cap = ali_cap;
-    BTRY(hipMalloc((void**)&a.node_pair, (size_t)gn * a.node_cap * 4));
-    BTRY(hipMalloc((void**)&a.node_next, (size_t)gn * a.node_cap * 4));
+    // node pool: a slice per pair for the one-wave kernels; ONE pool handed out in chunks for the several-wave kernel (a pair
+    // that needs ten times the average takes it from the pairs that need a tenth)
+    size_t pool_nodes = (size_t)gn * a.node_cap;
+    if (pw) {
+      a.n_pools = (uint32_t)((pool_nodes + 0xFFFF0000u - 1) / 0xFFFF0000u);          // 32-bit node indices: < 2^32 nodes per pool
+      a.n_chunks = (uint32_t)std::max<size_t>(1, pool_nodes / a.n_pools / kChunkNodes);
+      pool_nodes = (size_t)a.n_pools * a.n_chunks * kChunkNodes;
+      BTRY(hipMalloc((void**)&a.chunk_next, 4 * (size_t)a.n_pools));
+      BTRY(hipMemsetAsync(a.chunk_next, 0, 4 * (size_t)a.n_pools, ctx->stream));
+    }
+    BTRY(hipMalloc((void**)&a.node_pair, pool_nodes * 4));
+    BTRY(hipMalloc((void**)&a.node_next, pool_nodes * 4));
     BTRY(hipMalloc((void**)&a.head, (size_t)gn * a.ali_cap * 4));
     BTRY(hipMalloc((void**)&a.score, (size_t)gn * a.ali_cap * 4));
     if (pw) {
@@ -805,7 +823,7 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
       n_out[p] = 0;
       if (status[p] == kParSerial) { status[p] = 0; serial_todo.push_back(p); deferred[g] = 1; continue; }
       if (status[p] == ALN_E_OVERFLOW && !last_round &&
-          ((uint32_t)hout[4 * g + 1] >= a.node_cap - 64u || (uint32_t)hout[4 * g] + 64u >= a.ali_cap)) { again.push_back(p); deferred[g] = 1; continue; }
+          (pw || (uint32_t)hout[4 * g + 1] >= a.node_cap - 64u || (uint32_t)hout[4 * g] >= a.ali_cap)) { again.push_back(p); deferred[g] = 1; continue; }
       if (status[p] != 0) continue;
       const int n_as = hout[4 * g];
       sc.resize(n_as);
@@ -839,7 +857,8 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
     if (pairs) BTRY(hipMalloc((void**)&d_lists, sel.size() * (size_t)pair_stride * 8));
     BTRY(hipMemcpyAsync(d_sel, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     BTRY(hipEventRecord(evs[2], ctx->stream));
-    hipLaunchKernelGGL(enum_unroll_all_kernel, dim3(K, gn), dim3(64), 0, ctx->stream, a.node_pair, a.node_next, a.head, a.node_cap, a.ali_cap,
+    hipLaunchKernelGGL(enum_unroll_all_kernel, dim3(K, gn), dim3(64), 0, ctx->stream, a.node_pair, a.node_next, a.head,
+                       pw ? (size_t)a.n_chunks * kChunkNodes : (size_t)a.node_cap, pw ? (int)a.n_pools : 0, a.ali_cap,
                        d_sel, K, d_list, b->d_path, b->path_stride, b->d_res, d_lists, d_lens, pairs ? pair_stride : (1 << 30));
     BTRY(hipGetLastError());
     BTRY(hipEventRecord(evs[3], ctx->stream));
@@ -860,6 +879,14 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
     BTRY(hipEventElapsedTime(&ms0, evs[0], evs[1]));
     BTRY(hipEventElapsedTime(&ms1, evs[2], evs[3]));
     b->enum_search_ms += ms0; b->enum_unroll_ms += ms1;
+    if (ctx->hints.enum_debug) {
+      uint32_t used = 0;
+      if (pw) hipMemcpy(&used, a.chunk_next, 4, hipMemcpyDeviceToHost);      // (pool 0)
+      long long nodes = 0, slots = 0; int novf = 0;
+      for (int g = 0; g < gn; ++g) { nodes += (uint32_t)hout[4 * g + 1]; slots += hout[4 * g]; novf += hout[4 * g + 2] != 0; }
+      fprintf(stderr, "[enumerate_all] group of %d pairs, %d waves/pair, node_cap %u ali_cap %u: search %.2f ms, unroll %.2f ms, again %zu, serial %zu; chunks %u of %u, nodes %lld, slots %lld, failed %d\n",
+              gn, pw, a.node_cap, a.ali_cap, ms0, ms1, again.size(), serial_todo.size(), used, a.n_chunks, nodes, slots, novf);
+    }
     free_group();
     return ALN_OK;
   };
@@ -875,6 +902,7 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
                               (pairs ? (size_t)K * pair_stride * 8 : 0) + (cr ? (size_t)a0.sort_limit * a0.cr_tpad * 2 + (size_t)a0.cr_tpad * 4 : 0);
       size_t gmax = std::max<size_t>(1, kPoolBudget / per_pair);
       if (round == 0 && pass == 0) gmax = ids_all.size();               // the caller sized round 0
+      gmax = (ids_all.size() + (ids_all.size() + gmax - 1) / gmax - 1) / ((ids_all.size() + gmax - 1) / gmax);   // groups of equal size
       for (size_t g0 = 0; g0 < ids_all.size(); g0 += gmax) {
         const int gn = (int)std::min(gmax, ids_all.size() - g0);
         const int rcg = run_group(ids_all.data() + g0, gn, round == max_round, pw0 ? par_waves(b, noa->kind, gn) : 0);

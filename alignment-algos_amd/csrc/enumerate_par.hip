@@ -36,12 +36,18 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   __shared__ int s_head, s_tail, s_done, s_status;
   __shared__ unsigned s_nodes, s_slots;
+  __shared__ unsigned long long s_alloc;  // node allocator of this pair: current chunk << 32 | nodes used in it
+  __shared__ int s_lock;
   __shared__ uint16_t s_chunk[16][136];   // per wave: the blocks of a branch node's candidate row / column that can hold a passing candidate
   {
     const size_t bi = blockIdx.x;
     pair = a.pair_list ? a.pair_list[bi] : pair + (int)bi;
-    a.node_pair += bi * a.node_cap; a.node_next += bi * a.node_cap;
     a.head += bi * a.ali_cap; a.score += bi * a.ali_cap;
+    {                                                                 // node pool of this workgroup (shared with every n_pools-th pair)
+      const size_t pool = bi % a.n_pools;
+      a.node_pair += pool * (size_t)a.n_chunks * kChunkNodes; a.node_next += pool * (size_t)a.n_chunks * kChunkNodes;
+      a.chunk_next += pool;
+    }
     a.task += bi * (size_t)a.ali_cap * kTaskWords;
     a.slot_info += bi * (size_t)a.ali_cap * 3;
     a.flags += (size_t)(a.pair_list ? pair : (int)bi) * (size_t)a.flags_stride;
@@ -82,7 +88,9 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
 
   const uint32_t qcap = a.ali_cap;                    // ring of task records (every pending task owns a distinct slot, so <= ali_cap pend)
   if (threadIdx.x == 0) {
-    s_head = 0; s_tail = 1; s_done = 0; s_status = 0; s_nodes = 0u; s_slots = (unsigned)a.first_slot + 1u;   // as.push_back(SingleAlignment())  cw.h:82 / ucw.h:78
+    s_head = 0; s_tail = 1; s_done = 0; s_status = 0; s_nodes = 0u; s_lock = 0;
+    s_slots = (unsigned)a.first_slot + 1u;             // as.push_back(SingleAlignment())  cw.h:82 / ucw.h:78
+    s_alloc = (unsigned long long)kChunkNodes;        // "current chunk is full": the first allocation fetches one
     uint32_t* tk = a.task;                                                            // branch(final cell, seed slot)  cw.h:92 / ucw.h:86
     st_w(tk + 0, ((uint32_t)(Q - 1) << 16) | (uint32_t)(T - 1)); st_w(tk + 1, (uint32_t)a.first_slot); st_w(tk + 2, kNoNode);
     st_w(tk + 3, __float_as_uint(0.f)); st_w(tk + 4, 1u);
@@ -92,13 +100,32 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
   __syncthreads();
 
   auto fail = [&](int code) { if (lane == 0) atomicCAS(&s_status, 0, code); };
-  // n consecutive trie nodes for this wave; kNoNode: the pool is exhausted (status set)
+  // n <= 64 consecutive trie nodes for this wave, out of the pair's current chunk of the launch-wide pool; kNoNode: the pool is
+  // exhausted (status set).  Chunk and offset come from ONE 64-bit LDS atomic, so a wave can never pair an old offset with a new
+  // chunk; the wave that finds the chunk full fetches the next one under a lock (one device-scope atomic per 65536 nodes).
   auto alloc_nodes = [&](int n) -> uint32_t {
-    uint32_t b = 0;
-    if (lane == 0) b = atomicAdd(&s_nodes, (unsigned)n);
-    b = (uint32_t)__shfl((int)b, 0);
-    if (b + (uint32_t)n > a.node_cap) { fail(ALN_E_OVERFLOW); return kNoNode; }
-    return b;
+    uint32_t b = kNoNode;
+    if (lane == 0) {
+      for (int spin = 0; spin < (1 << 22); ++spin) {
+        const unsigned long long v = atomicAdd(&s_alloc, (unsigned long long)n);
+        const uint32_t chunk = (uint32_t)(v >> 32), off = (uint32_t)v;
+        if (off + (uint32_t)n <= kChunkNodes) { b = chunk * kChunkNodes + off; atomicAdd(&s_nodes, (unsigned)n); break; }
+        if (__hip_atomic_load(&s_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) break;
+        if (atomicCAS(&s_lock, 0, 1) == 0) {
+          const unsigned long long cur = __hip_atomic_load(&s_alloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if ((uint32_t)(cur >> 32) == chunk && (uint32_t)cur + 64u > kChunkNodes) {        // still the full chunk: replace it
+            const uint32_t c = __hip_atomic_fetch_add(a.chunk_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c >= a.n_chunks) atomicCAS(&s_status, 0, ALN_E_OVERFLOW);
+            else __hip_atomic_store(&s_alloc, (unsigned long long)c << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          __hip_atomic_store(&s_lock, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      if (b == kNoNode) atomicCAS(&s_status, 0, ALN_E_OVERFLOW);
+    }
+    return (uint32_t)__shfl((int)b, 0);
   };
 
   // Every wave takes tickets on its own: s_head = next ticket to take, s_tail = next ticket to hand out (a task's children are
@@ -219,15 +246,16 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
         const int n = __popcll(m);
         const int nnew = n - (first ? 1 : 0);
         uint32_t bt = 0, bn = 0, bs = 0;
+        bn = alloc_nodes(n);
+        if (bn == kNoNode) { dead = true; return; }
         if (lane == 0) {
           bt = (uint32_t)atomicAdd(&s_tail, n);
-          bn = atomicAdd(&s_nodes, (unsigned)n);
           if (nnew) bs = atomicAdd(&s_slots, (unsigned)nnew);
         }
-        bt = (uint32_t)__shfl((int)bt, 0); bn = (uint32_t)__shfl((int)bn, 0); bs = (uint32_t)__shfl((int)bs, 0);
+        bt = (uint32_t)__shfl((int)bt, 0); bs = (uint32_t)__shfl((int)bs, 0);
         if (nnew && bs + (uint32_t)nnew > a.user_limit) { fail(kParSerial); dead = true; return; }   // the serial order decides what user_limit cuts
         const uint32_t pending = bt + (uint32_t)n - (uint32_t)__hip_atomic_load(&s_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (pending + 64u > qcap || bn + (uint32_t)n > a.node_cap || bs + (uint32_t)nnew > a.ali_cap) {
+        if (pending + 64u > qcap || bs + (uint32_t)nnew > a.ali_cap) {
           fail(ALN_E_OVERFLOW); dead = true; return;
         }
         if ((m >> lane) & 1ull) {
