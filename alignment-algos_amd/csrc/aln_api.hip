@@ -175,6 +175,7 @@ void aln_batch_destroy(aln_batch* b) {
   hipFree(b->d_res); hipFree(b->d_table32); hipFree(b->d_tablef); hipFree(b->d_tgi); hipFree(b->d_tge);
   hipFree(b->d_path); hipFree(b->d_bounds); hipFree(b->d_xscratch); hipFree(b->d_tagq); hipFree(b->d_tagstate); hipFree(b->d_deltabR); hipFree(b->d_pair_deloff);
   if (b->h_path_pin) hipHostFree(b->h_path_pin);
+  for (auto& sc : b->enum_scratch) hipFree(sc.p);
   if (b->h_res_pin) hipHostFree(b->h_res_pin); hipFree(b->d_tcn); hipFree(b->d_deltab); hipFree(b->d_deltab_off); hipFree(b->d_instab);
   for (int k = 0; k < 2; ++k) { if (b->h_slot[k]) hipHostFree(b->h_slot[k]); if (b->slot_ev[k]) hipEventDestroy(b->slot_ev[k]); }
   for (int k = 0; k < aln_batch::kEvRing; ++k) { if (b->ring0[k]) hipEventDestroy(b->ring0[k]); if (b->ring1[k]) hipEventDestroy(b->ring1[k]); }

@@ -37,6 +37,7 @@ const HintDef kDefs[] = {
     {"enum_pool_retries", "ALN_ENUM_POOL_RETRIES", false, &aln_hints::enum_pool_retries},
     {"enum_waves", "ALN_ENUM_WAVES", false, &aln_hints::enum_waves},
     {"enum_debug", "ALN_ENUM_DEBUG", false, &aln_hints::enum_debug},
+    {"enum_keep_pools", "ALN_ENUM_KEEP_POOLS", false, &aln_hints::enum_keep_pools},
     {"plane_row_align", "ALN_PLANE_ROW_ALIGN", false, &aln_hints::plane_row_align},
 };
 

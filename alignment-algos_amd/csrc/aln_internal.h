@@ -77,6 +77,7 @@ struct aln_hints {
   int score_packed = 1;      // 0: one query per wave in aln_score_all_vs_all
   int plane_row_align = 8;   // cells a plane row is padded to when a batch is created (8, 16, 32 or 64)
   int64_t enum_node_cap = 0; // trie nodes of aln_batch_enumerate (0 = default)
+  int enum_keep_pools = 1;   // 1: aln_batch_enumerate_all keeps its device pools with the batch (freed with it); 0: frees them when it returns
   int enum_debug = 0;        // 1: aln_batch_enumerate_all reports every group of pairs it searches on stderr
   int enum_waves = 0;        // cw / ucw search: waves per pair (enumerate_par.hip); 0 = by the number of pairs, 1 = the one-wave kernel
   int enum_pool_retries = 2; // aln_batch_enumerate_all: times a pair whose pools overflowed is searched again with 4 x the capacity
@@ -139,6 +140,9 @@ struct aln_batch {
   hipEvent_t ring0[kEvRing] = {}, ring1[kEvRing] = {};
   long n_builds = 0;
   float enum_search_ms = 0.f, enum_unroll_ms = 0.f;   // last aln_batch_enumerate_all
+  // device pools of aln_batch_enumerate_all, kept between calls (hint enum_keep_pools): a hipMalloc of tens of GB costs seconds
+  struct Scratch { void* p = nullptr; size_t bytes = 0; };
+  Scratch enum_scratch[8];
   std::vector<int32_t> enum_usage;                    // ... and what every pair's search used of its pools
   // aln_batch_optimal_enqueue / _collect: two pinned result slots
   aln::PairResult* h_slot[2] = {nullptr, nullptr};

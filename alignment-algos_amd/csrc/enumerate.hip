@@ -324,6 +324,8 @@ __global__ void enumerate_cr_kernel(const PairDesc* __restrict__ pairs, int pair
 
 // ---------------------------------------------------------------------------------------------------------
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -669,6 +671,22 @@ __global__ __launch_bounds__(64) void enum_unroll_all_kernel(const uint32_t* __r
 }
 }  // namespace aln
 
+namespace aln {
+// {score, parent slot, t0, candidate} of every slot of every finished set, packed in set order of the launch: one D2H copy
+__global__ __launch_bounds__(256) void enum_pack_sets_kernel(const float* __restrict__ score, const uint32_t* __restrict__ slot_info,
+                                                            uint32_t ali_cap, const int64_t* __restrict__ off, uint32_t* __restrict__ out) {
+  const int g = blockIdx.x;
+  const int64_t o = off[g];
+  const int n = (int)(off[g + 1] - o);
+  for (int k = threadIdx.x; k < n; k += 256) {
+    uint32_t* r = out + (size_t)(o + k) * 4;
+    r[0] = __float_as_uint(score[(size_t)g * ali_cap + k]);
+    if (slot_info) { const uint32_t* si = slot_info + ((size_t)g * ali_cap + k) * 3; r[1] = si[0]; r[2] = si[1]; r[3] = si[2]; }
+    else { r[1] = 0u; r[2] = 0u; r[3] = 0u; }
+  }
+}
+}  // namespace aln
+
 extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const uint8_t* flags, int32_t flags_stride,
                                        uint32_t node_cap_per_pair, uint32_t ali_cap_per_pair, int32_t K, int32_t* n_out, float* scores,
                                        int32_t* lengths, int32_t* pairs, int32_t pair_stride, int32_t* status) {
@@ -704,9 +722,10 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   EnumArgs a = a0;
   int32_t *d_out = nullptr, *d_sel = nullptr, *d_lists = nullptr, *d_lens = nullptr, *d_list = nullptr;
   auto free_group = [&]() {
-    hipFree(a.node_pair); hipFree(a.node_next); hipFree(a.head); hipFree(a.score); hipFree(a.stack); hipFree(a.uid);
-    hipFree(a.cr_ali); hipFree(a.cr_reg); hipFree(a.task); hipFree(a.slot_info); hipFree(a.chunk_next);
-    hipFree(d_out); hipFree(d_sel); hipFree(d_lists); hipFree(d_lens); hipFree(d_list);
+    // (node_pair, node_next, head, score, task, slot_info, d_lists are the batch's: b->enum_scratch)
+    hipFree(a.stack); hipFree(a.uid);
+    hipFree(a.cr_ali); hipFree(a.cr_reg); hipFree(a.chunk_next);
+    hipFree(d_out); hipFree(d_sel); hipFree(d_lens); hipFree(d_list);
     a.node_pair = a.node_next = a.head = nullptr; a.score = nullptr; a.stack = nullptr; a.uid = nullptr; a.cr_ali = nullptr; a.cr_reg = nullptr;
     a.task = a.slot_info = a.chunk_next = nullptr;
     d_out = d_sel = d_lists = d_lens = d_list = nullptr;
@@ -714,6 +733,7 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   auto cleanup = [&]() {
     free_group();
     hipFree(d_flags); hipFree(d_bmr); hipFree(d_bmc);
+    if (!ctx->hints.enum_keep_pools) for (auto& sc : b->enum_scratch) { hipFree(sc.p); sc.p = nullptr; sc.bytes = 0; }
     for (auto ev : evs) if (ev) hipEventDestroy(ev);
   };
 #define BTRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(e_); cleanup(); return ALN_E_HIP; } } while (0)
@@ -758,7 +778,22 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   std::vector<int32_t> again, serial_todo;
   // one group of pairs: search, sortSet, unroll.  use_par: the several-waves-per-pair kernel (cw / ucw); a pair whose set outgrows
   // user_limit comes back as kParSerial and is searched again, with the same capacities, by the one-wave kernel.
+  // the large pools live with the batch (slot k of b->enum_scratch grows to the largest request)
+  auto scratch = [&](int k, size_t bytes, void** out) -> hipError_t {
+    aln_batch::Scratch& sc = b->enum_scratch[k];
+    if (sc.bytes < bytes) {
+      hipFree(sc.p); sc.p = nullptr; sc.bytes = 0;
+      hipError_t e = hipMalloc(&sc.p, bytes);
+      if (e != hipSuccess) return e;
+      sc.bytes = bytes;
+    }
+    *out = sc.p;
+    return hipSuccess;
+  };
   auto run_group = [&](const int32_t* ids, int gn, bool last_round, int pw) -> int {
+    double tm[6] = {0, 0, 0, 0, 0, 0};                       // enum_debug: host seconds of the group's phases
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    tm[0] = now();
     a = a0;
     a.node_cap = node_cap; a.ali_cap = ali_cap;
     // node pool: a slice per pair for the one-wave kernels; ONE pool handed out in chunks for the several-wave kernel (a pair
@@ -771,14 +806,14 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
       BTRY(hipMalloc((void**)&a.chunk_next, 4 * (size_t)a.n_pools));
       BTRY(hipMemsetAsync(a.chunk_next, 0, 4 * (size_t)a.n_pools, ctx->stream));
     }
-    BTRY(hipMalloc((void**)&a.node_pair, pool_nodes * 4));
-    BTRY(hipMalloc((void**)&a.node_next, pool_nodes * 4));
-    BTRY(hipMalloc((void**)&a.head, (size_t)gn * a.ali_cap * 4));
-    BTRY(hipMalloc((void**)&a.score, (size_t)gn * a.ali_cap * 4));
+    BTRY(scratch(0, pool_nodes * 4, (void**)&a.node_pair));
+    BTRY(scratch(1, pool_nodes * 4, (void**)&a.node_next));
+    BTRY(scratch(2, (size_t)gn * a.ali_cap * 4, (void**)&a.head));
+    BTRY(scratch(3, (size_t)gn * a.ali_cap * 4, (void**)&a.score));
     if (pw) {
-      BTRY(hipMalloc((void**)&a.task, (size_t)gn * a.ali_cap * kTaskWords * 4));
+      BTRY(scratch(4, (size_t)gn * a.ali_cap * kTaskWords * 4, (void**)&a.task));
       BTRY(hipMemsetAsync(a.task, 0, (size_t)gn * a.ali_cap * kTaskWords * 4, ctx->stream));   // ready words: ticket + 1, never 0
-      BTRY(hipMalloc((void**)&a.slot_info, (size_t)gn * a.ali_cap * 12));
+      BTRY(scratch(5, (size_t)gn * a.ali_cap * 12, (void**)&a.slot_info));
     } else {
       BTRY(hipMalloc((void**)&a.stack, (size_t)gn * a.stack_cap * frame_words * 4));
     }
@@ -791,6 +826,7 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
     BTRY(hipMalloc((void**)&d_list, (size_t)gn * 4));
     BTRY(hipMemcpyAsync(d_list, ids, (size_t)gn * 4, hipMemcpyHostToDevice, ctx->stream));
     a.flags = d_flags; a.out = d_out; a.pair_list = d_list;
+    tm[1] = now();
     BTRY(hipEventRecord(evs[0], ctx->stream));
     if (cr)
       hipLaunchKernelGGL(enumerate_cr_kernel, dim3(gn), dim3(64), cr_lds_bytes(a), ctx->stream, b->d_pairs, 0, proto,
@@ -814,47 +850,85 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
     BTRY(hipMemcpyAsync(hout.data(), d_out, hout.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
     BTRY(hipStreamSynchronize(ctx->stream));
     // per pair: sortSet on (score, index) keys, pick the survivors
+    tm[2] = now();
     sel.assign((size_t)gn * K, -1);
     std::vector<char> deferred(gn, 0);
+    std::vector<int64_t> off(gn + 1, 0);                    // the sets' slots, packed: pair g's slot k is record off[g] + k
     for (int g = 0; g < gn; ++g) {
       const int p = ids[g];
       for (int w = 0; w < 4; ++w) b->enum_usage[(size_t)p * 4 + w] = hout[4 * g + w];
       status[p] = hout[4 * g + 2] ? hout[4 * g + 2] : res[p].status;
       n_out[p] = 0;
+      off[g + 1] = off[g];
       if (status[p] == kParSerial) { status[p] = 0; serial_todo.push_back(p); deferred[g] = 1; continue; }
       if (status[p] == ALN_E_OVERFLOW && !last_round &&
           (pw || (uint32_t)hout[4 * g + 1] >= a.node_cap - 64u || (uint32_t)hout[4 * g] >= a.ali_cap)) { again.push_back(p); deferred[g] = 1; continue; }
-      if (status[p] != 0) continue;
-      const int n_as = hout[4 * g];
-      sc.resize(n_as);
-      if (pw) {                                             // set order from the slot tree (enumerate_par.hip)
-        info.resize((size_t)n_as * 3); raw.resize(n_as);
-        BTRY(hipMemcpyAsync(info.data(), a.slot_info + (size_t)g * a.ali_cap * 3, info.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-        BTRY(hipMemcpyAsync(raw.data() + 1, a.score + (size_t)g * a.ali_cap + 1, (size_t)(n_as - 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
-        BTRY(hipStreamSynchronize(ctx->stream));
-        slot_order(n_as, 1, info.data(), old_of_new);
-        for (int k = 1; k < n_as; ++k) sc[k] = raw[old_of_new[k]];
-      } else {
-        BTRY(hipMemcpy(sc.data() + 1, a.score + (size_t)g * a.ali_cap + 1, (size_t)(n_as - 1) * 4, hipMemcpyDeviceToHost));
+      if (status[p] != 0) { deferred[g] = 2; continue; }   // (2: nothing to order, lengths still reported)
+      off[g + 1] = off[g] + hout[4 * g];
+    }
+    // one gather + one copy instead of two small copies per pair: {score, parent, t0, candidate} per slot
+    const size_t total_slots = (size_t)off[gn];
+    std::vector<uint32_t> packed(total_slots * 4);
+    if (total_slots) {
+      uint32_t* d_packed = nullptr; int64_t* d_off = nullptr;
+      BTRY(scratch(7, total_slots * 16, (void**)&d_packed));
+      BTRY(hipMalloc((void**)&d_off, (size_t)(gn + 1) * 8));
+      hipError_t e1 = hipMemcpyAsync(d_off, off.data(), (size_t)(gn + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+      if (e1 == hipSuccess) {
+        hipLaunchKernelGGL(enum_pack_sets_kernel, dim3(gn), dim3(256), 0, ctx->stream, a.score, pw ? a.slot_info : (const uint32_t*)nullptr, a.ali_cap, d_off, d_packed);
+        e1 = hipGetLastError();
       }
-      sc[0] = b->islocal ? res[p].best : res[p].corner;
-      std::vector<SortKey> keys(n_as);
-      for (int k = 0; k < n_as; ++k) { keys[k].score = sc[k]; keys[k].idx = k; }
+      if (e1 == hipSuccess) e1 = hipMemcpyAsync(packed.data(), d_packed, total_slots * 16, hipMemcpyDeviceToHost, ctx->stream);
+      if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);
+      hipFree(d_off);
+      BTRY(e1);
+    }
+    // per pair, on host threads: the reference's set order (slot tree), then AlignmentSet::sortSet on (score, index) keys
+    {
       const int mx = noa->number_suboptimal;
-      if (mx >= n_as) std::sort(keys.begin(), keys.end());
-      else if (mx > 0) { std::partial_sort(keys.begin(), keys.begin() + mx, keys.end()); keys.erase(keys.begin() + mx, keys.end()); }
-      int keep = (int)keys.size();
-      if (keep > K) { status[p] = ALN_E_OVERFLOW; keep = K; }     // the caller's K slots are too few for this set
-      n_out[p] = keep;
-      for (int k = 0; k < keep; ++k) {
-        sel[(size_t)g * K + k] = pw ? old_of_new[keys[k].idx] : keys[k].idx;
-        scores[(size_t)p * K + k] = keys[k].score;
+      auto work = [&](int tid, int nthreads) {
+        std::vector<int32_t> order; std::vector<float> scv; std::vector<SortKey> keys; std::vector<uint32_t> inf;
+        for (int g = tid; g < gn; g += nthreads) {
+          if (deferred[g]) continue;
+          const int p = ids[g];
+          const int n_as = hout[4 * g];
+          const uint32_t* rec = packed.data() + (size_t)off[g] * 4;
+          scv.resize(n_as);
+          if (pw) {                                           // set order from the slot tree (enumerate_par.hip)
+            inf.resize((size_t)n_as * 3);
+            for (int k = 0; k < n_as; ++k) { inf[3 * k] = rec[4 * k + 1]; inf[3 * k + 1] = rec[4 * k + 2]; inf[3 * k + 2] = rec[4 * k + 3]; }
+            slot_order(n_as, 1, inf.data(), order);
+            for (int k = 1; k < n_as; ++k) { uint32_t u = rec[4 * (size_t)order[k]]; memcpy(&scv[k], &u, 4); }
+          } else {
+            for (int k = 1; k < n_as; ++k) { uint32_t u = rec[4 * (size_t)k]; memcpy(&scv[k], &u, 4); }
+          }
+          scv[0] = b->islocal ? res[p].best : res[p].corner;
+          keys.resize(n_as);
+          for (int k = 0; k < n_as; ++k) { keys[k].score = scv[k]; keys[k].idx = k; }
+          if (mx >= n_as) std::sort(keys.begin(), keys.end());
+          else if (mx > 0) { std::partial_sort(keys.begin(), keys.begin() + mx, keys.end()); keys.erase(keys.begin() + mx, keys.end()); }
+          int keep = (int)keys.size();
+          if (keep > K) { status[p] = ALN_E_OVERFLOW; keep = K; }     // the caller's K slots are too few for this set
+          n_out[p] = keep;
+          for (int k = 0; k < keep; ++k) {
+            sel[(size_t)g * K + k] = pw ? order[keys[k].idx] : keys[k].idx;
+            scores[(size_t)p * K + k] = keys[k].score;
+          }
+        }
+      };
+      const int nthreads = (int)std::max(1u, std::min({std::thread::hardware_concurrency(), 16u, (unsigned)((total_slots >> 14) + 1)}));
+      if (nthreads == 1) work(0, 1);
+      else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; ++t) th.emplace_back(work, t, nthreads);
+        for (auto& t : th) t.join();
       }
     }
     // unroll every survivor on the device
+    tm[3] = now();
     BTRY(hipMalloc((void**)&d_sel, sel.size() * 4));
     BTRY(hipMalloc((void**)&d_lens, sel.size() * 4));
-    if (pairs) BTRY(hipMalloc((void**)&d_lists, sel.size() * (size_t)pair_stride * 8));
+    if (pairs) BTRY(scratch(6, sel.size() * (size_t)pair_stride * 8, (void**)&d_lists));
     BTRY(hipMemcpyAsync(d_sel, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     BTRY(hipEventRecord(evs[2], ctx->stream));
     hipLaunchKernelGGL(enum_unroll_all_kernel, dim3(K, gn), dim3(64), 0, ctx->stream, a.node_pair, a.node_next, a.head,
@@ -869,7 +943,7 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
     BTRY(hipStreamSynchronize(ctx->stream));
     for (int g = 0; g < gn; ++g) {
       const int p = ids[g];
-      if (deferred[g]) continue;
+      if (deferred[g] == 1) continue;
       for (int k = 0; k < K; ++k) lengths[(size_t)p * K + k] = hlens[(size_t)g * K + k];
       if (pairs && !in_place)
         BTRY(hipMemcpy(pairs + (size_t)p * K * pair_stride * 2, d_lists + (size_t)g * K * pair_stride * 2, (size_t)K * pair_stride * 8,
@@ -879,6 +953,7 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
     BTRY(hipEventElapsedTime(&ms0, evs[0], evs[1]));
     BTRY(hipEventElapsedTime(&ms1, evs[2], evs[3]));
     b->enum_search_ms += ms0; b->enum_unroll_ms += ms1;
+    tm[4] = now();
     if (ctx->hints.enum_debug) {
       uint32_t used = 0;
       if (pw) hipMemcpy(&used, a.chunk_next, 4, hipMemcpyDeviceToHost);      // (pool 0)
@@ -886,6 +961,8 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
       for (int g = 0; g < gn; ++g) { nodes += (uint32_t)hout[4 * g + 1]; slots += hout[4 * g]; novf += hout[4 * g + 2] != 0; }
       fprintf(stderr, "[enumerate_all] group of %d pairs, %d waves/pair, node_cap %u ali_cap %u: search %.2f ms, unroll %.2f ms, again %zu, serial %zu; chunks %u of %u, nodes %lld, slots %lld, failed %d\n",
               gn, pw, a.node_cap, a.ali_cap, ms0, ms1, again.size(), serial_todo.size(), used, a.n_chunks, nodes, slots, novf);
+      fprintf(stderr, "[enumerate_all]   host seconds: alloc %.3f, search + sync %.3f, sets %.3f, unroll + copy %.3f\n", tm[1] - tm[0], tm[2] - tm[1],
+              tm[3] - tm[2], tm[4] - tm[3]);
     }
     free_group();
     return ALN_OK;

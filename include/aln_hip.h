@@ -176,7 +176,7 @@ int aln_ctx_synchronize(aln_ctx* ctx);
 int aln_has_gfx950(void);
 /* Tuning / kernel-selection hints of ONE context.  A context reads its defaults from the environment once, when it is created
  * (ALN_NO_TAG_KERNEL, ALN_NO_H16, ALN_NO_KEY16, ALN_TAG_ALT_PRIO, ALN_TAG_SEGMENTS, ALN_DP_VARIANT="NW,R[,X]", ALN_EXACT_NO_TILES,
- * ALN_EXACT_LITERAL, ALN_EXACT_ALT_PRIO, ALN_SCORE_NO_PACKED, ALN_ENUM_NODE_CAP, ALN_TAG_LAG, ALN_TAG_SOLO, ALN_TAG_BITS, ALN_PLANE_ROW_ALIGN, ALN_ENUM_POOL_RETRIES, ALN_ENUM_WAVES, ALN_ENUM_DEBUG); launches never read the environment.  Keys:
+ * ALN_EXACT_LITERAL, ALN_EXACT_ALT_PRIO, ALN_SCORE_NO_PACKED, ALN_ENUM_NODE_CAP, ALN_TAG_LAG, ALN_TAG_SOLO, ALN_TAG_BITS, ALN_PLANE_ROW_ALIGN, ALN_ENUM_POOL_RETRIES, ALN_ENUM_WAVES, ALN_ENUM_DEBUG, ALN_ENUM_KEEP_POOLS); launches never read the environment.  Keys:
  *   "tag_kernel" "h16" "key16"     1/0: tagged-key kernel / uint16 score plane / 16-bit key layout allowed (results identical)
  *   "tag_alt_prio"                  1/0: row-alternating wave priority in the tagged kernel (a scheduling hint; pays when launches
  *                                   follow each other on one stream, loses when launches of several contexts overlap);
@@ -192,6 +192,8 @@ int aln_has_gfx950(void);
  *   "enum_waves"                    ConstrainedNearOptimal / UnconstrainedNearOptimal search: waves per pair (2..16, enumerate_par.hip);
  *                                   1 = the one-wave kernel; 0 (default) = 16.  Same sets, same order.
  *   "enum_debug"                    1: aln_batch_enumerate_all reports every group of pairs it searches (pools, times, retries) on stderr
+ *   "enum_keep_pools"               1 (default): aln_batch_enumerate_all keeps its device pools with the batch until the batch is destroyed
+ *                                   (allocating tens of GB costs seconds); 0: frees them when it returns
  *   "enum_pool_retries"             aln_batch_enumerate_all: how often a pair whose pools overflowed is searched again with four
  *                                   times the capacity (default 2)
  * Unknown key -> ALN_E_ARG.  No hint changes any result. */
