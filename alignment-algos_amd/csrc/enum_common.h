@@ -33,6 +33,7 @@ struct EnumArgs {
   uint32_t* chunk_next; // [n_pools] next free chunk (device counters)
   uint32_t n_chunks;    // chunks per pool
   uint32_t n_pools;
+  int int_sums;         // 1: similarities, gaps and scores are integers below 2^24 (the tagged DP kernel's own precondition): sums in any order
   const float* rowmax;  // [pairs of the batch][bm_rows][nbt] block maxima of the score plane (enum_blockmax_kernel), or nullptr
   const float* colmax;  // [pairs of the batch][bm_cols][nbq]
   int bm_rows, bm_cols, nbt, nbq, bm_pair0;   // (arrays start at pair bm_pair0 of the batch)

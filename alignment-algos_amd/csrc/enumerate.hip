@@ -495,6 +495,7 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   a.flags = d_flags;
   a.ptr_mode = b->ptr_mode;
   a.h_mode = b->h_mode;
+  a.int_sums = b->ptr_mode != 0;
   a.out = d_out;
   float *d_bmr = nullptr, *d_bmc = nullptr;
   if (pw) { int rcb = make_blockmax(b, a, pair, 1, &d_bmr, &d_bmc); if (rcb) { cleanup(); return rcb; } }
@@ -711,6 +712,7 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   a0.cand_cap = (uint32_t)(b->maxQ + b->maxT);
   a0.stack_cap = (uint32_t)(b->maxQ + b->maxT + 8);
   a0.ptr_mode = b->ptr_mode; a0.h_mode = b->h_mode;
+  a0.int_sums = b->ptr_mode != 0;                      // tagged planes exist only for integer tables and gaps with bounded scores
   a0.flags_stride = flags ? flags_stride : 0;
   if (cr && !set_cr_params(a0, noa, b->maxT)) return ALN_E_ARG;
   const size_t frame_words = ks ? 8 + 4 * a0.k_limit : kFrameWords;

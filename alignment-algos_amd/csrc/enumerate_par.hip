@@ -81,6 +81,12 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
   bind_table_model(e, proto, pd);
   e.S = Sbase ? Sbase + pd.plane_off : nullptr;
   auto HV = [&](int i, int j) -> float { return load_score(Hbase, pd.plane_off, ld, i, j, a.h_mode); };
+  // DPMatrix::getSim: from the LDS copies (ds_read, not the flat loads a generic EvalDev pointer costs) for a substitution table
+  auto SIM = [&](int i, int j) -> float {
+    if (!sub) return dev_sim(e, i, j);
+    if (i <= 0 || j <= 0 || i >= Q - 1 || j >= T - 1) return 0.f;
+    return l_tab[(int)l_qc[i] * 32 + (int)l_tc[j]];
+  };
 
   const float top = HV(Q - 1, T - 1);
   float thr = (1.f - a.delta_ratio) * top;       // cw.h:86-88
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
   __syncthreads();
 
   auto fail = [&](int code) { if (lane == 0) atomicCAS(&s_status, 0, code); };
-  // n <= 64 consecutive trie nodes for this wave, out of the pair's current chunk of the launch-wide pool; kNoNode: the pool is
+  // n <= 512 consecutive trie nodes for this wave, out of the pair's current chunk of the launch-wide pool; kNoNode: the pool is
   // exhausted (status set).  Chunk and offset come from ONE 64-bit LDS atomic, so a wave can never pair an old offset with a new
   // chunk; the wave that finds the chunk full fetches the next one under a lock (one device-scope atomic per 65536 nodes).
   auto alloc_nodes = [&](int n) -> uint32_t {
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
         if (__hip_atomic_load(&s_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) break;
         if (atomicCAS(&s_lock, 0, 1) == 0) {
           const unsigned long long cur = __hip_atomic_load(&s_alloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if ((uint32_t)(cur >> 32) == chunk && (uint32_t)cur + 64u > kChunkNodes) {        // still the full chunk: replace it
+          if ((uint32_t)(cur >> 32) == chunk && (uint32_t)cur + 512u > kChunkNodes) {        // still the full chunk: replace it
             const uint32_t c = __hip_atomic_fetch_add(a.chunk_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (c >= a.n_chunks) atomicCAS(&s_status, 0, ALN_E_OVERFLOW);
             else __hip_atomic_store(&s_alloc, (unsigned long long)c << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -126,6 +132,19 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
       if (b == kNoNode) atomicCAS(&s_status, 0, ALN_E_OVERFLOW);
     }
     return (uint32_t)__shfl((int)b, 0);
+  };
+
+  // Each wave keeps a reserve of nodes it took from the pair's chunk (512 at a time), so that a step of a walk costs no LDS atomic.
+  uint32_t w_base = 0, w_left = 0;
+  auto take_nodes = [&](int n) -> uint32_t {
+    if (w_left < (uint32_t)n) {                          // (what is left of the old reserve stays unused: < 64 nodes per 512)
+      const uint32_t b = alloc_nodes(512);
+      if (b == kNoNode) return kNoNode;
+      w_base = b; w_left = 512;
+    }
+    const uint32_t b = w_base;
+    w_base += (uint32_t)n; w_left -= (uint32_t)n;
+    return b;
   };
 
   // Every wave takes tickets on its own: s_head = next ticket to take, s_tail = next ticket to hand out (a task's children are
@@ -179,7 +198,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
 
     // as[slot].prepend(q0,t0); as[slot].prepend(0,0); score += H(q0,t0)   (cw.h:100-108 / ucw.h:93-101), then publish the slot
     auto base_case = [&]() {
-      const uint32_t b = alloc_nodes(2);
+      const uint32_t b = take_nodes(2);
       if (b == kNoNode) return;
       if (lane == 0) {
         a.node_pair[b] = ((uint32_t)q0 << 16) | (uint32_t)t0; a.node_next[b] = hd;
@@ -204,7 +223,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
           if (!stop) {
             const uint32_t p = load_ptr_word(Pbase, pd.plane_off, ld, q, t, a.ptr_mode);
             decode_ptr(p, a.ptr_mode, q, t, pq, pt);
-            sv = dev_sim(e, q, t);
+            sv = SIM(q, t);
           }
           const bool diag = !stop && pq == q - 1 && pt == t - 1;
           const unsigned long long m_end = __ballot(!diag);
@@ -212,7 +231,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
           const bool gap_cell = F < 64 && !(((__ballot(stop)) >> F) & 1ull);
           const int n_proc = gap_cell ? F + 1 : F;
           if (n_proc == 0) break;
-          const uint32_t b = alloc_nodes(n_proc);
+          const uint32_t b = take_nodes(n_proc);
           if (b == kNoNode) { dead = true; break; }
           if (lane < n_proc) {
             a.node_pair[b + lane] = ((uint32_t)q << 16) | (uint32_t)t;
@@ -223,7 +242,14 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
             if (q - pq == 1) g = dev_deletion(e, pt, t);
             else g = dev_insertion(e, pq, q, pt, t);
           }
-          sc = add_in_path_order(sc, sv, n_proc);            // path order: fp32 is not associative
+          if (a.int_sums) {                                   // integer-valued scores below 2^24: any order gives the reference's sum
+            float part = lane < n_proc ? sv : 0.f;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+            sc += part;
+          } else {
+            sc = add_in_path_order(sc, sv, n_proc);            // path order: fp32 is not associative
+          }
           if (gap_cell) {
             sc -= __shfl(g, F);
             q0 = __shfl(pq, F); t0 = __shfl(pt, F);
@@ -236,7 +262,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
       }
       // ---- branch(q0,t0,slot) ----
       if (cw && force) { is_branch = false; continue; }                     // cw.h:205-209: opt_path(..., true)
-      const float r = sc + dev_sim(e, q0, t0);
+      const float r = sc + SIM(q0, t0);
       const int ndel = t0 - 2, nins = q0 - 2;
       const int ncand = 1 + ndel + nins;
       bool first = true;                                                    // the first accepted candidate continues in `slot`
@@ -246,7 +272,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
         const int n = __popcll(m);
         const int nnew = n - (first ? 1 : 0);
         uint32_t bt = 0, bn = 0, bs = 0;
-        bn = alloc_nodes(n);
+        bn = take_nodes(n);
         if (bn == kNoNode) { dead = true; return; }
         if (lane == 0) {
           bt = (uint32_t)atomicAdd(&s_tail, n);
