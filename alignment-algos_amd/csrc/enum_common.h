@@ -68,4 +68,15 @@ __device__ __forceinline__ float add_in_path_order(float sc, float sv, int n) {
   return sc;
 }
 
+// Sum of an int over the wave, in every lane: six DPP adds (quad swaps, half-row and row mirrors, row broadcasts) and a readlane.
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);    // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);    // row_mirror: every lane holds its row's sum
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);    // row_bcast15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);    // row_bcast31 into rows 2 and 3: lane 63 holds the total
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 }  // namespace aln

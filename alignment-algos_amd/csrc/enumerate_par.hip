@@ -243,10 +243,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
             else g = dev_insertion(e, pq, q, pt, t);
           }
           if (a.int_sums) {                                   // integer-valued scores below 2^24: any order gives the reference's sum
-            float part = lane < n_proc ? sv : 0.f;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
-            sc += part;
+            sc += (float)wave_sum_i32(lane < n_proc ? (int)sv : 0);
           } else {
             sc = add_in_path_order(sc, sv, n_proc);            // path order: fp32 is not associative
           }
@@ -361,7 +358,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
           g = (len < 1 || (fins && (q == 0 || q0 == Q - 1))) ? 0.f : e.gi + e.ge * (float)(len - 1);
           return in;
         };
-        constexpr int kTrip = 8;
+        constexpr int kTrip = 4;                              // (a near-optimal search rarely keeps more than the match and 2-3 blocks)
         for (int c0 = 0; c0 < total && !dead; c0 += kTrip) {
           float fsc[kTrip];
 #pragma unroll
