@@ -132,12 +132,13 @@ def secondary_configs(aln_amd, ctx, alphabet, table, qs, ts, length):
     b.dp_submatrix(alphabet, table, aln_amd.LOCAL, 11, 1, aln_amd.FWD, aln_amd.DP_FAST)
     ctx.synchronize()
     flags = make_subopt_regions(length + 2, 10)
-    best = None
+    best = first = None
     for rep in range(2):
         t0 = time.perf_counter()
         n_out, scores, lengths, _, status = b.enumerate_all("cw", 256, 0.01, flags, K=258, node_cap=1 << 23, ali_cap=1 << 16,
                                                             want_pairs=False, raise_on_overflow=False)
         dt = time.perf_counter() - t0
+        first = dt if first is None else first
         best = dt if best is None else min(best, dt)
     sm, um = b.last_enum_ms()
     created, nodes = b.last_enum_usage()
@@ -148,7 +149,11 @@ def secondary_configs(aln_amd, ctx, alphabet, table, qs, ts, length):
                  "value_is": "alignments the searches create (the reference's as.size() before sortSet keeps NUM_SUBOPT) / wall seconds",
                  "alignments_created": int(created.sum()), "alignments_kept": int(n_out.sum()), "trie_nodes": int(nodes.sum()),
                  "aligned_pairs_emitted": int(lengths[lengths > 0].sum()),
-                 "search_kernel_ms": round(sm, 3), "unroll_kernel_ms": round(um, 3), "pairs_overflowed": int((status != 0).sum())}
+                 "search_kernel_ms": round(sm, 3), "unroll_kernel_ms": round(um, 3), "pairs_overflowed": int((status != 0).sum()),
+                 "first_call_seconds": round(first, 4),
+                 "search": "enumerate_par_kernel: 16 waves per pair take sub-searches from a per-pair ticket ring; block maxima of the score "
+                           "plane prune the candidate scans; the set order is rebuilt from the slot tree on host threads; `seconds` is the "
+                           "best of two calls, `first_call_seconds` the one that also allocates the node / task pools (kept with the batch)"}
     b.close()
     # ---- config 3: Hmap2Eval profile-profile, global, exact-order DP
     n_prof = 64
