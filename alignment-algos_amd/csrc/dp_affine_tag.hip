@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
   // ---- static per-column constants -----------------------------------------------------------------
   int inm[R][X];        // -1 for interior columns 1 .. T-2, else 0
   int code4[R][X];      // byte offset of the column's residue in a table row
-  int GK[R][X];         // (ge*c) << 13 | P_DEL | (2047 - c): d' + GK = key of A(c) = D + ge*c as a deletion source
+  int GK[R][X];         // ((ge*c) << 13 | P_DEL | (2047 - c)) - P_MATCH: dk + GK = key of A(c) = D + ge*c as a deletion source
   int EK[R][X];         // (ge*c + gi - ge) << 13: E(c+1) = prefmax - EK
   bool inrange[R];
 #pragma unroll
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
       if (c < T) code = tc[c];
       code4[r][x] = code * 4;
       inm[r][x] = ((unsigned)(c - 1) < (unsigned)(T - 2)) ? -1 : 0;
-      GK[r][x] = ((ge * c) * (1 << KB)) | P_DEL | (TAGMAX - (c & TAGMAX));
+      GK[r][x] = (((ge * c) * (1 << KB)) | P_DEL | (TAGMAX - (c & TAGMAX))) - P_MATCH;   // (dk carries the match bits: see below)
       EK[r][x] = (ge * c + gi - ge) * (1 << KB);
     }
   }
@@ -134,7 +134,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
   int codeB4 = kCodeTail * 4;
   if (NW > 1 && CB < T) codeB4 = tc[CB] * 4;
 
-  int dk[R][X];         // D[i-1][c] << 13 (low bits zero)
+  int dk[R][X];         // D[i-1][c] << 13 | P_MATCH: the row's scores, already dressed as match candidates of the next row (the
+                        // split of a finished key is one v_and_or_b32 either way; the next row's `m | P_MATCH` per cell is gone)
   int gmx[R][X];        // running max over k of key(D[k][c] + ge*k, insertion, 2047-k)
   int cvk[R];           // lane-exclusive prefix key of the row in dk (A-space), per group
   int ak[R][X];         // A-space keys of the row in dk: dk + GK (column 0 / wave firsts handled where they are used)
@@ -143,9 +144,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
   for (int r = 0; r < R; ++r) {
     cvk[r] = NEGK;
 #pragma unroll
-    for (int x = 0; x < X; ++x) { dk[r][x] = 0; gmx[r][x] = NEGK; pf[r][x] = kNullPtr; }
+    for (int x = 0; x < X; ++x) { dk[r][x] = P_MATCH; gmx[r][x] = NEGK; pf[r][x] = kNullPtr; }
   }
-  int lmax = 0; uint32_t lpos = 0;
+  int lmax = P_MATCH; uint32_t lpos = 0;
   // Skewed exchange.  Only later waves depend on earlier ones (deletion scans run left to right, the boundary cell of wave v is
   // the first column of wave v+1; nothing flows back), so wave w may run behind wave v < w by any number of rows.  With
   // lag = L > 0 wave w handles row (it - L*w) in iteration `it`: what wave v wrote for that row (iteration row + L*v) is at least L
@@ -188,7 +189,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
 #pragma unroll
         for (int x = 0; x < X; x += 4)
           *reinterpret_cast<float4*>(H + ro + GW * r + x) =
-              make_float4((float)dk[r][x] * sc, (float)dk[r][x + 1] * sc, (float)dk[r][x + 2] * sc, (float)dk[r][x + 3] * sc);
+              make_float4((float)(dk[r][x] - P_MATCH) * sc, (float)(dk[r][x + 1] - P_MATCH) * sc, (float)(dk[r][x + 2] - P_MATCH) * sc,
+                          (float)(dk[r][x + 3] - P_MATCH) * sc);
       }
       store_words(pw, rsP, vo16 + 2 * GW * r);
     }
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
       if (sync) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (w > 0) {
         int fk = NEGK;                                      // prefix over columns 1 .. W0-1
-        int d0 = 0; uint32_t p0 = kNullPtr;
+        int d0 = P_MATCH; uint32_t p0 = kNullPtr;
 #pragma unroll
         for (int v = 0; v < NW - 1; ++v) {
           if (v < w) {                                      // wave-uniform; one ds_read_b128 per earlier wave
@@ -234,14 +236,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
             fk = max(fk, t.x);
             if (v < w - 1) {
               const int Cn = (v + 1) * GW * R;
-              fk = max(fk, t.y + (((ge * Cn) * (1 << KB)) | P_DEL | (TAGMAX - Cn)));
+              fk = max(fk, t.y + ((((ge * Cn) * (1 << KB)) | P_DEL | (TAGMAX - Cn)) - P_MATCH));
             } else {
               d0 = t.y; p0 = (uint32_t)t.z;
             }
           }
         }
         if (lane == 0) { dk[0][0] = d0; pf[0][0] = p0; ak[0][0] = d0 + GK[0][0]; }
-        const int f2 = max(fk, d0 + (((ge * W0) * (1 << KB)) | P_DEL | (TAGMAX - W0)));
+        const int f2 = max(fk, d0 + ((((ge * W0) * (1 << KB)) | P_DEL | (TAGMAX - W0)) - P_MATCH));
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           int nv = max(f2, cvk[r]);
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
       }
     }
     if (LOCAL) {
-      int rm = 0;
+      int rm = P_MATCH;
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -317,14 +319,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
       int v = sK - cost;
       if (LOCAL) v = max(v, 0);
       const bool in = (unsigned)(c - 1) < (unsigned)(T - 2);
-      dkv = in ? v : 0;
+      dkv = (in ? v : 0) | P_MATCH;
       pv = in ? (uint32_t)(c == 1 ? P_MATCH : ORIGIN_DEL) : kNullPtr;
     };
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int x = 0; x < X; ++x) row1(cb + GW * r + x, tab_at(qrow, code4[r][x]), dk[r][x], pf[r][x]);
-    int dB = 0; uint32_t pB = kNullPtr;
+    int dB = P_MATCH; uint32_t pB = kNullPtr;
     if (NW > 1) row1(CB, tab_at(qrow, codeB4), dB, pB);
     const int4 none[NW > 1 ? NW - 1 : 1] = {};
     finish_row(1, dB, pB, true, none);
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
     rowv_next = tab_at(code_n1 * 128, lane_row4);
     code_n1 = (int)qcs[min(i + 2, Q - 1)];                                      // (clamped: only rows <= Q-2 are consumed)
     const int FK = (gi + ge * (i - 2)) * (1 << KB);                                   // F = gmx - FK
-    const int RK = ((ge * (i - 1)) * (1 << KB)) | P_INS | (TAGMAX - (i - 1));         // key(D[i-1][c] + ge (i-1), insertion from row i-1)
+    const int RK = (((ge * (i - 1)) * (1 << KB)) | P_INS | (TAGMAX - (i - 1))) - P_MATCH;   // dk + RK = key(D[i-1][c] + ge (i-1), insertion from row i-1)
     const int colK = prm.free_ins ? 0 : FK;                                     // column 1: one insertion from the origin
 
     int bk[R][X];
@@ -388,17 +390,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
         if (r == 0 && x == 0) A = (cb == 0) ? NEGK : A;     // column 0 is never a source (dpmatrix.h:459 starts at t0+1)
         const int e = pv - EK[r][x];
         const int f = gmx[r][x] - FK;
-        bk[r][x] = max(max(m | P_MATCH, e), f);             // v_max3_i32: match > deletion > insertion on equal values
+        bk[r][x] = max(max(m, e), f);                       // v_max3_i32: match > deletion > insertion on equal values
         pv = max(pv, A);
       }
     }
     // boundary target (first column of the next wave), finished by this wave's lane 63
-    int dB = 0; uint32_t pB = kNullPtr;
+    int dB = P_MATCH; uint32_t pB = kNullPtr;
     if (NW > 1) {
       int kh = bk[R - 1][X - 1] + svB;
       if (LOCAL) kh = max(kh, ZKEY);
       const bool in = CB <= T - 2;
-      dB = in ? (kh & ~LOW) : 0;
+      dB = in ? ((kh & ~LOW) | P_MATCH) : P_MATCH;
       pB = in ? (uint32_t)(kh & LOW) : kNullPtr;
     }
     // vertical state: row i-1 becomes an insertion source for row i+1
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
         if (r == 0 && x == 1) sK1 = sK;
         int kh = ((x == 0) ? uk : bk[r][x - 1]) + sK;
         if (LOCAL) kh = max(kh, ZKEY);
-        dk[r][x] = kh & ~LOW;
+        dk[r][x] = (kh & ~LOW) | P_MATCH;                    // v_and_or_b32
         pf[r][x] = (KBT == 16) ? (uint32_t)kh : (uint32_t)(kh & LOW);   // KB = 16: the store takes the low half of the whole key
       }
       if (masked) {                                          // one scalar branch per group; only the groups holding column 0/1 or columns >= T-1 pay
@@ -433,11 +435,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
           int v1 = sK1 - colK;
           if (LOCAL) v1 = max(v1, 0);
           const bool is1 = cb == 0;
-          dk[0][1] = is1 ? v1 : dk[0][1]; pf[0][1] = is1 ? (uint32_t)ORIGIN_INS : pf[0][1];
+          dk[0][1] = is1 ? (v1 | P_MATCH) : dk[0][1]; pf[0][1] = is1 ? (uint32_t)ORIGIN_INS : pf[0][1];
         }
 #pragma unroll
         for (int x = 0; x < X; ++x) {
-          dk[r][x] &= inm[r][x];                             // columns 0 and >= T-1: score 0, null pointer
+          dk[r][x] = (dk[r][x] & inm[r][x]) | P_MATCH;       // columns 0 and >= T-1: score 0, null pointer
           pf[r][x] |= ~(uint32_t)inm[r][x];
         }
       }
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int x = 0; x < X; ++x) { dk[r][x] = 0; pf[r][x] = kNullPtr; }
+      for (int x = 0; x < X; ++x) { dk[r][x] = P_MATCH; pf[r][x] = kNullPtr; }
     store_row(Q - 1);
   }
 
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
     int m = lmax;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o));
-    uint32_t p = (lmax == m && m > 0) ? lpos : 0xFFFFFFFFu;
+    uint32_t p = (lmax == m && (m >> KB) > 0) ? lpos : 0xFFFFFFFFu;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) p = min(p, (uint32_t)__shfl_xor((int)p, o));
     if (NW > 1) {
