@@ -331,7 +331,7 @@ int run_dp(aln_batch* b, bool simplane_integral) {
     fast = fast_path_legal(b, sub ? b->h_table.data() : nullptr, b->alpha_n, &b->gap, simplane_integral);
     tagged = fast && sub && tag_path_legal(b, b->h_table.data(), b->alpha_n, &b->gap) && ctx->hints.tag_kernel;
   }
-  if (b->algo == ALN_DP_FAST && !fast) return ALN_E_NOT_INTEGRAL;
+  if (b->algo == ALN_DP_FAST && !fast) return (b->maxld > 8192 && b->gap.model == ALN_GAP_AFFINE_CONST) ? ALN_E_TOO_LONG : ALN_E_NOT_INTEGRAL;
   // pointer dialect of the P plane (aln_device.h decode_ptr): 0 = packed 32-bit, 1 / 2 = 16-bit tagged words with 11 / 12 tag bits
   b->ptr_mode = tagged ? (tag_path_bits(b, b->h_table.data(), b->alpha_n, &b->gap) == 12 ? 2 : 1) : 0;
   b->h_mode = (tagged && b->islocal && ctx->hints.h16 && tag_h16_legal(b)) ? 1 : 0;   // local scores of the tagged path are integers in [0, 65535]

@@ -364,6 +364,7 @@ __global__ __launch_bounds__(64 * NW) void dp_affine_int_kernel(
 // every similarity and gap value an integer, and every intermediate magnitude below 2^24.
 bool fast_path_legal(const aln_batch* b, const float* table, int n, const aln_gap* gap, bool simplane_integral) {
   if (gap->model != ALN_GAP_AFFINE_CONST) return false;
+  if (b->maxld > 8192) return false;            // the row-sweep kernels hold a row in registers: 4 waves x 8 groups x 256 columns at most
   float gi = gap->gap_init, ge = gap->gap_extn;
   if (!(gi == (float)(int)gi) || !(ge == (float)(int)ge)) return false;
   if (gi < 0 || ge < 0 || gi > 65536.f || ge > 4096.f) return false;

@@ -880,3 +880,35 @@ def test_solo_kernel_vs_oracle_and_tagged(blosum62):
             D, PQ, PT = c[0][p]
             assert np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (mode, gi, p)
             assert np.array_equal(PQ, PQ0) and np.array_equal(PT, PT0), (mode, gi, p)
+
+
+def test_templates_beyond_the_row_sweep_kernels(blosum62):
+    """The reference has no length limit (dpmatrix.h:250-259).  The O(n^2) row-sweep kernels hold a row in registers (tagged keys:
+    4096 columns, plain int32: 8192); wider templates run in the exact-order kernel under DP_AUTO (same results, its O(n^3)
+    scans), DP_FAST says ALN_E_TOO_LONG.  Checked against the oracle with a short query."""
+    alpha, table = blosum62
+    q, t = homolog_pair(99001, 8400, sub_rate=0.2, indel=4)
+    q = q[:28]
+    for tl, algo, want in ((8190, aln_amd.DP_FAST, "dp_affine_int"), (8400, aln_amd.DP_AUTO, "dp_exact")):
+        tt = t[:tl]
+        b = aln_amd.Batch(gpu_util.ctx(), [q], [tt])
+        b.dp_submatrix(alpha, table, aln_amd.LOCAL, 11, 1, aln_amd.FWD, algo)
+        assert want in b.kernel_name(), b.kernel_name()
+        S = orc.sim_submatrix(q, tt, alpha, table)
+        rc, D0, PQ0, PT0 = orc.dp_build(S, orc.Gap(aln_amd.LOCAL, 11, 1))
+        D, PQ, PT = b.get_cells(0)
+        assert np.array_equal(D.view(np.uint32), D0.view(np.uint32)), tl
+        assert np.array_equal(PQ, PQ0) and np.array_equal(PT, PT0), tl
+        scores, lists, status = b.optimal()
+        rc2, sc, pl = orc.optimal(D0, PQ0, PT0, True)
+        assert status[0] == 0 and bits_of(scores[0]) == bits_of(sc) and np.array_equal(lists[0], pl)
+        b.close()
+    b = aln_amd.Batch(gpu_util.ctx(), [q], [t])
+    with pytest.raises(aln_amd.AlnError) as ei:
+        b.dp_submatrix(alpha, table, aln_amd.LOCAL, 11, 1, aln_amd.FWD, aln_amd.DP_FAST)
+    assert ei.value.code == aln_amd.E_TOO_LONG
+    b.close()
+
+
+def bits_of(x):
+    return int(np.float32(x).view(np.uint32))
