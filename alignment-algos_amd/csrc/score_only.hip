@@ -493,6 +493,49 @@ __global__ __launch_bounds__(64) void score_local_pk_kernel(ScoreArgs a, int n_r
 
 using namespace aln;
 
+// The general route: scores[(q - q_begin) * n_t + t] for the templates listed in `tlist`, through resident batches of full
+// DP builds (aln_batch_dp picks the kernel: tagged keys, int32 rows, exact-order scans) + Optimal's score — what the reference does
+// for every pair, kept for what the register-resident kernels above do not take: templates beyond 2048 columns, fractional tables
+// or gaps.  Pairs are grouped so that one group's planes stay below ~12 GB.
+static int score_through_batches(aln_ctx* ctx, const aln_seqs* queries, const aln_seqs* templates, const aln_submatrix* sub,
+                                 const aln_gap* gap, int32_t q_begin, int32_t q_end, const std::vector<int32_t>& tlist, float* scores) {
+  const int n_t = templates->n_seqs;
+  const size_t budget = (size_t)12 << 30;
+  aln_sim sim = aln_sim();
+  sim.kind = ALN_SIM_SUBMATRIX;
+  sim.sub = *sub;
+  std::vector<int32_t> qi, tix;
+  std::vector<float> sc;
+  std::vector<int32_t> st;
+  auto flush = [&]() -> int {
+    if (qi.empty()) return ALN_OK;
+    aln_batch* bb = nullptr;
+    int rc = aln_batch_create(ctx, queries, templates, (int32_t)qi.size(), qi.data(), tix.data(), 0, &bb);
+    if (rc == ALN_OK) rc = aln_batch_dp(bb, &sim, gap, ALN_FWD, ALN_DP_AUTO, 0);
+    sc.resize(qi.size()); st.resize(qi.size());
+    if (rc == ALN_OK) rc = aln_batch_optimal(bb, sc.data(), nullptr, nullptr, 0, st.data());
+    if (bb) aln_batch_destroy(bb);
+    if (rc != ALN_OK) return rc;
+    for (size_t k = 0; k < qi.size(); ++k) {
+      if (st[k] != 0) return st[k];
+      scores[(size_t)(qi[k] - q_begin) * n_t + tix[k]] = sc[k];
+    }
+    qi.clear(); tix.clear();
+    return ALN_OK;
+  };
+  size_t bytes = 0;
+  for (int32_t t : tlist) {
+    const size_t T = (size_t)(templates->offsets[t + 1] - templates->offsets[t]);
+    for (int32_t q = q_begin; q < q_end; ++q) {
+      const size_t Q = (size_t)(queries->offsets[q + 1] - queries->offsets[q]);
+      const size_t need = Q * (T + 16) * 8;
+      if (!qi.empty() && bytes + need > budget) { int rc = flush(); if (rc) return rc; bytes = 0; }
+      qi.push_back(q); tix.push_back(t); bytes += need;
+    }
+  }
+  return flush();
+}
+
 // The score Optimal reports for queries[q_begin .. q_end) against every template: scores[(q - q_begin) * n_t + t].
 // Replaces (q_end - q_begin) x n_t constructions of DPMatrix(q, t, AASubstitutionEval, fwd, align_type) + Optimal(align_type):
 // find_max for local alignments, the final cell's score for the four other align types.
@@ -507,7 +550,12 @@ extern "C" int aln_score_all_vs_all(aln_ctx* ctx, const aln_seqs* queries, const
   if (!sub->alphabet || !sub->table || sub->n < 1 || sub->n > 30) return ALN_E_ARG;
   ALN_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const float gi = gap->gap_init, ge = gap->gap_extn;
-  if (!(gi == (float)(int)gi) || !(ge == (float)(int)ge) || gi < 0 || ge < 0) return ALN_E_NOT_INTEGRAL;
+  std::vector<int32_t> every_t((size_t)templates->n_seqs);
+  for (int t = 0; t < templates->n_seqs; ++t) every_t[t] = t;
+  if (q_begin == q_end || templates->n_seqs == 0) return ALN_OK;
+  // fractional gaps or table values: full builds in the exact-order kernels (the reference's arithmetic), batch by batch
+  if (!(gi == (float)(int)gi) || !(ge == (float)(int)ge) || gi < 0 || ge < 0)
+    return score_through_batches(ctx, queries, templates, sub, gap, q_begin, q_end, every_t, scores);
   int idx[256];
   for (int i = 0; i < 256; ++i) idx[i] = -1;
   for (int i = 0; i < sub->n; ++i) idx[(unsigned char)sub->alphabet[i]] = i;
@@ -517,7 +565,7 @@ extern "C" int aln_score_all_vs_all(aln_ctx* ctx, const aln_seqs* queries, const
   for (int i = 0; i < sub->n; ++i)
     for (int j = 0; j < sub->n; ++j) {
       float v = sub->table[i * sub->n + j];
-      if (!(v == (float)(int)v)) return ALN_E_NOT_INTEGRAL;
+      if (!(v == (float)(int)v)) return score_through_batches(ctx, queries, templates, sub, gap, q_begin, q_end, every_t, scores);
       ti[i * 32 + j] = (int32_t)v;
       maxs = std::max(maxs, fabs((double)v));
     }
@@ -542,8 +590,9 @@ extern "C" int aln_score_all_vs_all(aln_ctx* ctx, const aln_seqs* queries, const
   int maxQ = 0, maxT = 0, rc;
   if ((rc = encode(queries, qc, maxQ)) != ALN_OK) return rc;
   if ((rc = encode(templates, tc, maxT)) != ALN_OK) return rc;
-  if (maxT > 2048 || maxQ > kMaxLen) return ALN_E_TOO_LONG;
-  if ((maxs + ge) * ((double)maxQ + maxT) + gi + maxs >= 8388608.0) return ALN_E_NOT_INTEGRAL;
+  if (maxT > kMaxLen || maxQ > kMaxLen) return ALN_E_TOO_LONG;
+  if ((maxs + ge) * ((double)maxQ + std::min(maxT, 2048)) + gi + maxs >= 8388608.0)
+    return score_through_batches(ctx, queries, templates, sub, gap, q_begin, q_end, every_t, scores);
   const int rows = q_end - q_begin, n_t = templates->n_seqs;
   if (rows == 0 || n_t == 0) return ALN_OK;
 
@@ -563,21 +612,23 @@ extern "C" int aln_score_all_vs_all(aln_ctx* ctx, const aln_seqs* queries, const
   a.q_begin = q_begin; a.n_t = n_t; a.gi = (int)gi; a.ge = (int)ge;
   // Templates are launched by length class: a wave sweeps 256 R columns, so a template of T columns needs
   // R = ceil(T / 256) groups; one launch per class keeps short templates from paying for the longest one.
-  std::vector<int32_t> order; std::vector<int> cls_begin(10, 0);
+  std::vector<int32_t> order, long_t; std::vector<int> cls_begin(10, 0);
   {
     std::vector<std::vector<int32_t>> by(9);
     for (int t = 0; t < n_t; ++t) {
       const int T = (int)(templates->offsets[t + 1] - templates->offsets[t]);
-      by[(T + 255) / 256].push_back(t);
+      if (T > 2048) long_t.push_back(t);            // beyond the register-resident kernels: full builds below
+      else by[(T + 255) / 256].push_back(t);
     }
     for (int r = 1; r <= 8; ++r) { cls_begin[r] = (int)order.size(); order.insert(order.end(), by[r].begin(), by[r].end()); }
     cls_begin[9] = (int)order.size();
   }
   STRY(hipMalloc((void**)&dsel, (size_t)n_t * 4));
-  STRY(hipMemcpyAsync(dsel, order.data(), (size_t)n_t * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (!order.empty()) STRY(hipMemcpyAsync(dsel, order.data(), order.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   // packed 16-bit lanes (two queries per wave) when every intermediate provably fits: best local score <= maxs * min(Q,T),
   // A keys add ge * column, the "minus infinity" -12000 must stay below every real candidate and clear of wrap-around
-  const double L = (double)std::max(maxQ, maxT), best = maxs * (double)std::min(maxQ, maxT);
+  const int fastT = std::min(maxT, 2048);                // (longer templates do not run in these kernels)
+  const double L = (double)std::max(maxQ, fastT), best = maxs * (double)std::min(maxQ, fastT);
   const bool packed = local && best + ge * L + maxs < 30000.0 && ge * L + gi + maxs < 8000.0 && maxs < 2048.0 && ctx->hints.score_packed;
   const dim3 block(64);
   // blockIdx.y is limited to 65535: walk the query rows in slabs.  The packed kernel pairs queries of similar length (a wave
@@ -653,5 +704,6 @@ extern "C" int aln_score_all_vs_all(aln_ctx* ctx, const aln_seqs* queries, const
   STRY(hipStreamSynchronize(ctx->stream));
 #undef STRY
   cleanup();
+  if (!long_t.empty()) return score_through_batches(ctx, queries, templates, sub, gap, q_begin, q_end, long_t, scores);
   return ALN_OK;
 }

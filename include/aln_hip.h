@@ -300,8 +300,10 @@ int aln_batch_last_enum_ms(aln_batch* b, float* search_ms, float* unroll_ms);
  * other align types (optimal.h:56-74) — for queries[q_begin..q_end) against EVERY template:
  * scores[(q - q_begin) * templates->n_seqs + t].  Replaces that many DPMatrix(q, t, AASubstitutionEval, fwd, align_type) +
  * Optimal constructions; nothing per cell is written to HBM.  A rank of a multi-GPU job calls it with its own block of query
- * rows.  ALN_GAP_AFFINE_CONST with integer values (else ALN_E_NOT_INTEGRAL), templates up to 2046 residues (else
- * ALN_E_TOO_LONG); local alignments whose values fit 15 bits run two queries per wave in packed 16-bit lanes. */
+ * rows.  ALN_GAP_AFFINE_CONST.  Integer table and gaps, templates up to 2046 residues: register-resident kernels
+ * (local alignments whose values fit 15 bits run two queries per wave in packed 16-bit lanes).  Anything else the reference would
+ * score — longer templates, fractional values — goes through resident batches of full builds (aln_batch_dp + Optimal) inside the
+ * same call, ~12 GB of planes at a time; sequences beyond 65534 residues: ALN_E_TOO_LONG. */
 int aln_score_all_vs_all(aln_ctx* ctx, const aln_seqs* queries, const aln_seqs* templates, const aln_submatrix* sub,
                          const aln_gap* gap, int32_t q_begin, int32_t q_end, float* scores);
 

@@ -87,11 +87,34 @@ def test_score_only_rejects_what_it_cannot_do(blosum62):
     alpha, table = blosum62
     ctx = gpu_util.ctx()
     with pytest.raises(aln_amd.AlnError) as ei:
-        aln_amd.score_all_vs_all(ctx, ["ACD"], ["ACD"], alpha, table, 4.73, 0.34)
-    assert ei.value.code == aln_amd.E_NOT_INTEGRAL
-    with pytest.raises(aln_amd.AlnError) as ei:
         aln_amd.score_all_vs_all(ctx, ["ACJ"], ["ACD"], alpha, table, 11, 1)
     assert ei.value.code == aln_amd.E_RESIDUE
+
+
+@pytest.mark.parametrize("mode", [3, 1, 4])
+def test_long_templates_and_fractional_gaps_go_through_full_builds(mode, blosum62):
+    """The reference scores any pair with any evaluator values (N x DPMatrix + Optimal).  What the register-resident kernels do
+    not take — templates beyond 2048 columns, fractional gaps — aln_score_all_vs_all computes through resident batches of full
+    builds (tagged / int32 / exact-order kernels) and Optimal's score, in the same call and the same output matrix."""
+    alpha, table = blosum62
+    qlens = [5, 120, 333, 90]
+    tlens = [300, 2047, 2048, 2600, 40, 3100]                 # two templates beyond the kernels' 2048 columns, among short ones
+    qs, ts = make_set(85000 + mode, qlens), make_set(86000 + mode, tlens)
+    qs[2] = ts[3][1000:1333]                                  # a homolog inside a long template
+    ctx = gpu_util.ctx()
+    for gi, ge in ((11, 1), (4.73, 0.34)):
+        got = aln_amd.score_all_vs_all(ctx, qs, ts, alpha, table, gi, ge, align_type=mode)
+        qi, ti = np.meshgrid(np.arange(len(qs)), np.arange(len(ts)), indexing="ij")
+        b = aln_amd.Batch(ctx, qs, ts, qi.reshape(-1), ti.reshape(-1))
+        b.dp_submatrix(alpha, table, mode, gi, ge)
+        want = (b.optimal(want_pairs=False)[0] if mode == 3 else b.corner_scores()).reshape(len(qs), len(ts))
+        b.close()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (mode, gi, np.argwhere(got != want)[:5])
+        for (i, j) in ((0, 0), (2, 3), (1, 5)):
+            S = orc.sim_submatrix(qs[i], ts[j], alpha, table)
+            rc, D, PQ, PT = orc.dp_build(S, orc.Gap(mode, gi, ge))
+            ref = orc.optimal(D, PQ, PT, True)[1] if mode == 3 else D[-1, -1]
+            assert np.float32(got[i, j]).view(np.uint32) == np.float32(ref).view(np.uint32), (mode, gi, i, j)
 
 
 def test_more_than_one_slab_of_query_rows(blosum62):
