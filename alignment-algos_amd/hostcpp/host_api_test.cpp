@@ -1,17 +1,22 @@
 // host_api_test.cpp — exercises the C++ host mirror end to end on the GPU (used by tests/test_gpu_hostcpp.py):
 //   profile <mode> <q.hmap> <t.hmap>      DPMatrix<HMAPSequence,SMAPSequence,Hmap2Eval> + Optimal -> score bits, pairs, probes
 //   aa <mode> <gi> <ge> <dir> <q> <t> <blosum>   DPMatrix<AASequence,...> fwd/rev + Optimal/Optimal_Rev + ucw, cells via getCell
+//   set <mode> <gi> <ge> <blosum> <q1> <t1> [<q2> <t2> ...]   DPMatrixSet (all pairs in one launch) against one DPMatrix per pair:
+//                                         cells, Optimal, ConstrainedNearOptimal — with AASubstitutionEval and with a plugin
 //   gn2 <mode> <q.hmap> <t.hmap> <seed>   DPMatrix<HMAPSequence,SMAPSequence,Gn2Eval> with synthetic structural members; prints the
 //                                         tables pre_calculate built (TAB name n v...) so a test can feed them to its checker
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <vector>
 #include "aa_seq.h"
 #include "aasubalib.h"
 #include "cw.h"
 #include "dpmatrix.h"
+#include "dpmatrix_set.h"
 #include "gn2_eval.h"
 #include "hmap2_eval.h"
 #include "optimal.h"
@@ -48,6 +53,76 @@ class SqrtGapEval : public Evaluator<S1, S2, SqrtGapEval<S1, S2> > {
   const AliParams* params;
   const SubstitutionMatrix* sub;
 };
+
+static unsigned fbits(float f);
+
+// A plugin that names its gap model (aln_describe_gaps): half-BLOSUM similarities (fractional -> a SimilarityMatrix plane per
+// pair, the exact-order kernels), constant affine gaps.
+template <class S1, class S2>
+class HalfBlosumEval : public Evaluator<S1, S2, HalfBlosumEval<S1, S2> > {
+ public:
+  HalfBlosumEval(const AliParams& p, const SubstitutionMatrix& m) : params(&p), sub(&m) {}
+  float similarity(const S1& q, const S2& t, int qi, int ti) const {
+    if (q[qi]->isHead() || q[qi]->isTail() || t[ti]->isHead() || t[ti]->isTail()) return 0.f;
+    return 0.5f * sub->score(q[qi]->olc, t[ti]->olc) + 0.25f;
+  }
+  float deletion(const S1&, const S2& t, int, int, int t1, int t2) const {
+    int len = t2 - t1 - 1;
+    if (len < 1) return 0.f;
+    if (free_end() && (t[t1]->isHead() || t[t2]->isTail())) return 0.f;
+    return params->gap_init_penalty + params->gap_extn_penalty * (float)(len - 1);
+  }
+  float insertion(const S1& q, const S2&, int q1, int q2, int, int) const {
+    int len = q2 - q1 - 1;
+    if (len < 1) return 0.f;
+    if (free_end() && (q[q1]->isHead() || q[q2]->isTail())) return 0.f;
+    return params->gap_init_penalty + params->gap_extn_penalty * (float)(len - 1);
+  }
+  void pre_calculate(const S1&, const S2&) const {}
+  void post_process(SimilarityMatrix&) const {}
+  void aln_describe_gaps(const S1&, const S2&, aln::GapDescription& g) const {
+    g.model = ALN_GAP_AFFINE_CONST; g.align_type = params->align_type;
+    g.gap_init = params->gap_init_penalty; g.gap_extn = params->gap_extn_penalty;
+  }
+ private:
+  bool free_end() const { return params->align_type == local || params->align_type == semi_local; }
+  const AliParams* params;
+  const SubstitutionMatrix* sub;
+};
+
+// DPMatrixSet against one DPMatrix per pair: every cell, the Optimal alignment, the ConstrainedNearOptimal set
+template <class Eval>
+static int compare_set(const char* tag, const std::vector<const AASequence*>& qv, const std::vector<const AASequence*>& tv, const Eval& ev, align_t type) {
+  DPMatrixSet<AASequence, AASequence, Eval> set(qv, tv, ev, fwd, type);
+  int bad = 0;
+  NOaliParams noa;
+  noa.number_suboptimal = 12; noa.delta_ratio = 0.2f;
+  for (size_t p = 0; p < set.size(); ++p) {
+    DPMatrix<AASequence, AASequence, Eval> dpm(*qv[p], *tv[p], ev, fwd, type);
+    const int Q = dpm.getQuerySize(), T = dpm.getTemplateSize();
+    for (int i = 0; i < Q; ++i)
+      for (int j = 0; j < T; ++j) {
+        const DPCell* a = dpm.getCell(i, j);
+        const DPCell b = set.getCell(p, i, j);
+        if (fbits(a->score) != fbits(b.score) || a->prev_query_idx != b.prev_query_idx || a->prev_template_idx != b.prev_template_idx) ++bad;
+      }
+    Optimal<AASequence, AASequence, Eval> opt(type);
+    AlignmentSet<AASequence, AASequence, Eval> as(dpm, opt);
+    typename DPMatrixSet<AASequence, AASequence, Eval>::Alignment o = set.optimal(p);
+    if (fbits(o.score) != fbits(as[0].score) || o.size() != as[0].size() || !std::equal(o.begin(), o.end(), as[0].begin())) ++bad;
+    if (fbits(set.scores()[p]) != fbits(as[0].score)) ++bad;
+    SuboptFlags fl(true, (size_t)T);
+    for (int k = T / 3; k < 2 * T / 3; ++k) fl.Set((unsigned)k, false);
+    ConstrainedNearOptimal<AASequence, AASequence, Eval> cno(noa, fl);
+    cno.enumerate(dpm, as);                     // (returns the sorted set)
+    std::vector<typename DPMatrixSet<AASequence, AASequence, Eval>::Alignment> es = set.enumerate(p, noa, &fl);
+    if (es.size() != as.size()) ++bad;
+    for (size_t k = 0; k < es.size() && k < as.size(); ++k)
+      if (fbits(es[k].score) != fbits(as[k].score) || es[k].size() != as[k].size() || !std::equal(es[k].begin(), es[k].end(), as[k].begin())) ++bad;
+  }
+  printf("SET %s pairs %d mismatches %d\n", tag, (int)set.size(), bad);
+  return bad;
+}
 
 static unsigned fbits(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 
@@ -122,6 +197,34 @@ int main(int argc, char** argv) {
         printf("\n");
       };
       tri("dist", t.distance); tri("vv_gi", ev.vv_gi); tri("vv_ge", ev.vv_ge); tri("vv_cd", ev.vv_cd);
+      return 0;
+    }
+    if (cmd == "set") {         // set <mode> <gi> <ge> <blosum> <q1> <t1> [<q2> <t2> ...]
+      AliParams p;
+      p.align_type = (align_t)atoi(argv[2]);
+      p.gap_init_penalty = (float)atof(argv[3]);
+      p.gap_extn_penalty = (float)atof(argv[4]);
+      BlosumMatrix blosum(argv[5]);
+      std::vector<AASequence*> own;
+      std::vector<const AASequence*> qv, tv;
+      for (int a = 6; a + 1 < argc; a += 2) {
+        AASequence* q = new AASequence; AASequence* t = new AASequence;
+        q->seq_name = "query"; t->seq_name = "templ";
+        q->append("^"); q->append(argv[a]); q->append("$");
+        t->append("^"); t->append(argv[a + 1]); t->append("$");
+        own.push_back(q); own.push_back(t); qv.push_back(q); tv.push_back(t);
+      }
+      AASubstitutionEval<AASequence, AASequence> ev(p, blosum);
+      HalfBlosumEval<AASequence, AASequence> hv(p, blosum);
+      int bad = compare_set("aasub", qv, tv, ev, p.align_type);
+      bad += compare_set("plugin", qv, tv, hv, p.align_type);
+      try {                       // an evaluator whose gap functions are tabulated per pair is refused, loudly
+        SqrtGapEval<AASequence, AASequence> sq(p, blosum);
+        DPMatrixSet<AASequence, AASequence, SqrtGapEval<AASequence, AASequence> > s2(qv, tv, sq, fwd, p.align_type);
+        printf("SET tables: no refusal\n"); ++bad;
+      } catch (std::string e) { printf("SET tables refused: %s\n", e.c_str()); }
+      for (size_t k = 0; k < own.size(); ++k) delete own[k];
+      printf(bad ? "SET FAILED\n" : "SET OK\n");
       return 0;
     }
     if (cmd == "plain") {       // plain <mode> <gi> <ge> <q> <t> <blosum>: the unmodified plugin above; prints H/PQ/PT, S and its gap tables

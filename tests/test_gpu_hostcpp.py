@@ -152,3 +152,21 @@ def test_aa_path_through_host_classes(mode, gi, ge, direction, blosum62):
             assert u["alis"][k]["uid"] == r["uid"]
             assert np.array_equal(u["alis"][k]["pairs"], r["pairs"])
             assert u["alis"][k]["identity"].view(np.uint32) == r["identity"].view(np.uint32)
+
+
+@pytest.mark.parametrize("mode,gi,ge", [(3, 11, 1), (1, 11, 1), (4, 4.73, 0.34)])
+def test_dpmatrix_set_equals_one_dpmatrix_per_pair(mode, gi, ge):
+    """hostcpp/dpmatrix_set.h (an extension: many DPMatrix builds in one launch) against the one-pair DPMatrix of the reference's
+    surface, pair by pair: every cell, Optimal's alignment and score, ConstrainedNearOptimal's sorted set — with
+    AASubstitutionEval (codes + table) and with a plugin that names its constant-affine gap model (a SimilarityMatrix plane per
+    pair); an evaluator whose gap functions must be tabulated per pair is refused."""
+    from aln_amd.synth import homolog_pair, random_pair
+    pairs = [homolog_pair(93000, 60, sub_rate=0.2, indel=3), random_pair(93001, 30, 45), homolog_pair(93002, 130, sub_rate=0.25, indel=4),
+             ("ACDEFG", "ACDFG"), homolog_pair(93003, 300, sub_rate=0.15, indel=5)]
+    args = ["set", mode, gi, ge, BLOSUM]
+    for q, t in pairs:
+        args += [q, t]
+    r = subprocess.run([EXE] + [str(a) for a in args], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "SET OK" in r.stdout and "mismatches 0" in r.stdout and "SET tables refused" in r.stdout, r.stdout + r.stderr
+    assert r.stdout.count("mismatches 0") == 2, r.stdout
