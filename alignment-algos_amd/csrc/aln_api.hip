@@ -175,6 +175,7 @@ void aln_batch_destroy(aln_batch* b) {
   hipFree(b->d_res); hipFree(b->d_table32); hipFree(b->d_tablef); hipFree(b->d_tgi); hipFree(b->d_tge);
   hipFree(b->d_path); hipFree(b->d_bounds); hipFree(b->d_xscratch); hipFree(b->d_tagq); hipFree(b->d_tagstate); hipFree(b->d_deltabR); hipFree(b->d_pair_deloff);
   if (b->h_path_pin) hipHostFree(b->h_path_pin);
+  if (b->h_stage_pin) hipHostFree(b->h_stage_pin);
   for (auto& sc : b->enum_scratch) hipFree(sc.p);
   if (b->h_res_pin) hipHostFree(b->h_res_pin); hipFree(b->d_tcn); hipFree(b->d_deltab); hipFree(b->d_deltab_off); hipFree(b->d_instab);
   for (int k = 0; k < 2; ++k) { if (b->h_slot[k]) hipHostFree(b->h_slot[k]); if (b->slot_ev[k]) hipEventDestroy(b->slot_ev[k]); }
@@ -224,13 +225,34 @@ int upload_submatrix(aln_batch* b, const aln_submatrix* sub) {
   int idx[256];
   for (int i = 0; i < 256; ++i) idx[i] = -1;
   for (int i = 0; i < sub->n; ++i) idx[(unsigned char)sub->alphabet[i]] = i;
-  std::vector<uint8_t> qc, tc;
-  int rc = encode(b->q_res, idx, qc);
+  // staging in PINNED memory kept with the batch: a hipMemcpyAsync from pageable vectors makes the runtime pin them on the fly,
+  // which cost ~25 ms per build of 1024 pairs (the whole DP kernel takes 3)
+  const size_t nq = b->q_res.size(), nt = b->t_res.size();
+  const size_t need = nq + nt + sizeof(float) * 1024 + sizeof(int32_t) * 1024 + 64;
+  if (b->h_stage_bytes < need) {
+    if (b->h_stage_pin) hipHostFree(b->h_stage_pin);
+    b->h_stage_pin = nullptr; b->h_stage_bytes = 0;
+    ALN_HIP_CHECK(ctx, hipHostMalloc((void**)&b->h_stage_pin, need, hipHostMallocDefault));
+    b->h_stage_bytes = need;
+  }
+  ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // an earlier upload may still read the staging buffer
+  uint8_t* qc = b->h_stage_pin;
+  uint8_t* tc = qc + nq;
+  float* tf = reinterpret_cast<float*>(b->h_stage_pin + ((nq + nt + 15) & ~(size_t)15));
+  int32_t* ti = reinterpret_cast<int32_t*>(tf + 1024);
+  auto enc = [&](const std::string& res, uint8_t* codes) -> int {
+    for (size_t k = 0; k < res.size(); ++k) {
+      const unsigned char ch = (unsigned char)res[k];
+      const int c = (ch == '^') ? kCodeHead : (ch == '$') ? kCodeTail : idx[ch];
+      if (c < 0) return ALN_E_RESIDUE;
+      codes[k] = (uint8_t)c;
+    }
+    return ALN_OK;
+  };
+  int rc = enc(b->q_res, qc);
   if (rc) return rc;
-  rc = encode(b->t_res, idx, tc);
+  rc = enc(b->t_res, tc);
   if (rc) return rc;
-  float tf[32 * 32];
-  int32_t ti[32 * 32];
   for (int i = 0; i < 32 * 32; ++i) { tf[i] = 0.f; ti[i] = 0; }
   for (int i = 0; i < sub->n; ++i)
     for (int j = 0; j < sub->n; ++j) {
@@ -240,12 +262,11 @@ int upload_submatrix(aln_batch* b, const aln_submatrix* sub) {
   b->h_table.assign(sub->table, sub->table + sub->n * sub->n);
   b->alpha_n = sub->n;
   b->alphabet.assign(sub->alphabet, sub->alphabet + sub->n);
-  ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_qcodes, qc.data(), qc.size(), hipMemcpyHostToDevice, ctx->stream));
-  ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_tcodes, tc.data(), tc.size(), hipMemcpyHostToDevice, ctx->stream));
-  ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_tablef, tf, sizeof tf, hipMemcpyHostToDevice, ctx->stream));
-  ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_table32, ti, sizeof ti, hipMemcpyHostToDevice, ctx->stream));
-  ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // the staging vectors die here
-  return ALN_OK;
+  ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_qcodes, qc, nq, hipMemcpyHostToDevice, ctx->stream));
+  ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_tcodes, tc, nt, hipMemcpyHostToDevice, ctx->stream));
+  ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_tablef, tf, sizeof(float) * 1024, hipMemcpyHostToDevice, ctx->stream));
+  ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_table32, ti, sizeof(int32_t) * 1024, hipMemcpyHostToDevice, ctx->stream));
+  return ALN_OK;             // (the staging buffer lives with the batch: no wait here, the launch follows on the same stream)
 }
 
 int upload_simplanes(aln_batch* b, const aln_sim* sim, bool* integral) {

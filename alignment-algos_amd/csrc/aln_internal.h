@@ -141,6 +141,7 @@ struct aln_batch {
   long n_builds = 0;
   float enum_search_ms = 0.f, enum_unroll_ms = 0.f;   // last aln_batch_enumerate_all
   // device pools of aln_batch_enumerate_all, kept between calls (hint enum_keep_pools): a hipMalloc of tens of GB costs seconds
+  uint8_t* h_stage_pin = nullptr; size_t h_stage_bytes = 0;   // pinned staging of residue codes + table (upload_submatrix)
   struct Scratch { void* p = nullptr; size_t bytes = 0; };
   Scratch enum_scratch[8];
   std::vector<int32_t> enum_usage;                    // ... and what every pair's search used of its pools
