@@ -5,6 +5,9 @@
 namespace aln {
 
 constexpr uint32_t kChunkNodes = 1u << 16;   // enumerate_par.hip: trie nodes a workgroup takes from the launch's pool at a time
+// which of a launch's node pools workgroup i uses: scattered, so that a pattern in the batch (bench.py alternates unrelated
+// and homologous pairs) does not put all heavy searches into one pool
+__host__ __device__ __forceinline__ uint32_t enum_pool_of(uint32_t i, uint32_t n_pools) { return ((i * 0x9E3779B1u) >> 12) % n_pools; }
 constexpr int kTaskWords = 8;    // enumerate_par.hip: cell, slot, trie head, score, kind/force, (pad)
 constexpr int kParSerial = -100; // enumerate_par.hip -> host: this pair's set outgrows user_limit, search it with the one-wave kernel
 constexpr int kFrameWords = 8;   // q0, t0, k0, cursor, curr_head, curr_score, r, (pad) — one active branch() invocation
@@ -77,6 +80,27 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);    // row_bcast15 into rows 1 and 3
   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);    // row_bcast31 into rows 2 and 3: lane 63 holds the total
   return __builtin_amdgcn_readlane(v, 63);
+}
+
+// Maximum of a float over the wave, in every lane (the DPP ladder of wave_sum_i32 with v_max_f32).
+__device__ __forceinline__ float wave_max_f32(float v) {
+  const float NEG = -3.0e38f;
+  auto dpp = [&](float x, int ctrl_sel) -> float {
+    const int xi = __float_as_int(x), ni = __float_as_int(NEG);
+    int r;
+    switch (ctrl_sel) {
+      case 0: r = __builtin_amdgcn_update_dpp(ni, xi, 0xB1, 0xF, 0xF, false); break;
+      case 1: r = __builtin_amdgcn_update_dpp(ni, xi, 0x4E, 0xF, 0xF, false); break;
+      case 2: r = __builtin_amdgcn_update_dpp(ni, xi, 0x141, 0xF, 0xF, false); break;
+      case 3: r = __builtin_amdgcn_update_dpp(ni, xi, 0x140, 0xF, 0xF, false); break;
+      case 4: r = __builtin_amdgcn_update_dpp(ni, xi, 0x142, 0xA, 0xF, false); break;
+      default: r = __builtin_amdgcn_update_dpp(ni, xi, 0x143, 0xC, 0xF, false); break;
+    }
+    return __int_as_float(r);
+  };
+  v = fmaxf(v, dpp(v, 0)); v = fmaxf(v, dpp(v, 1)); v = fmaxf(v, dpp(v, 2)); v = fmaxf(v, dpp(v, 3));
+  v = fmaxf(v, dpp(v, 4)); v = fmaxf(v, dpp(v, 5));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 }  // namespace aln

@@ -657,8 +657,8 @@ __global__ __launch_bounds__(64) void enum_unroll_all_kernel(const uint32_t* __r
     return;
   }
   if (threadIdx.x != 0) return;
-  // a slice per pair (one-wave kernels: n_pools = 0) or the pool workgroup p of enumerate_par.hip used (p % n_pools)
-  const size_t nbase = n_pools ? (size_t)(p % n_pools) * node_stride : (size_t)p * node_stride;
+  // a slice per pair (one-wave kernels: n_pools = 0) or the pool workgroup p of enumerate_par.hip used (enum_pool_of)
+  const size_t nbase = n_pools ? (size_t)enum_pool_of((uint32_t)p, (uint32_t)n_pools) * node_stride : (size_t)p * node_stride;
   const uint32_t* np_ = node_pair + nbase;
   const uint32_t* nn_ = node_next + nbase;
   uint32_t node = head[(size_t)p * ali_cap + idx];

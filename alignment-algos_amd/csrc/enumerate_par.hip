@@ -44,7 +44,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
     pair = a.pair_list ? a.pair_list[bi] : pair + (int)bi;
     a.head += bi * a.ali_cap; a.score += bi * a.ali_cap;
     {                                                                 // node pool of this workgroup (shared with every n_pools-th pair)
-      const size_t pool = bi % a.n_pools;
+      const size_t pool = enum_pool_of((uint32_t)bi, a.n_pools);
       a.node_pair += pool * (size_t)a.n_chunks * kChunkNodes; a.node_next += pool * (size_t)a.n_chunks * kChunkNodes;
       a.chunk_next += pool;
     }
@@ -474,8 +474,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
 
 
 // Block maxima of the score plane for the pruned scan above: colmax[t][bq] = max of H over rows 64 bq .. 64 bq + 63 of column t,
-// rowmax[q][bt] = max over columns 64 bt .. 64 bt + 63 of row q.  grid (row tiles, pairs), 256 threads; every cell is read twice
-// (the second time from L2): ~3 ms for 1024 pairs of 2002 x 2002.
+// rowmax[q][bt] = max over columns 64 bt .. 64 bt + 63 of row q.  grid (row tiles, pairs), 256 threads; every cell is read once.
 __global__ __launch_bounds__(256) void enum_blockmax_kernel(const PairDesc* __restrict__ pairs, const int32_t* __restrict__ pair_list, int pair0,
                                                            const float* __restrict__ Hbase, int h_mode, float* __restrict__ rowmax,
                                                            float* __restrict__ colmax, int bm_rows, int bm_cols, int nbt, int nbq, int bm_pair0) {
@@ -487,20 +486,22 @@ __global__ __launch_bounds__(256) void enum_blockmax_kernel(const PairDesc* __re
   const float NEG = -3.0e38f;
   float* cm = colmax + (size_t)(pair - bm_pair0) * bm_cols * nbq;
   float* rm = rowmax + (size_t)(pair - bm_pair0) * bm_rows * nbt;
-  for (int t = threadIdx.x; t < T; t += 256) {
-    float m = NEG;
-    for (int q = qa; q < qb; ++q) m = fmaxf(m, load_score(Hbase, pd.plane_off, ld, q, t, h_mode));
-    cm[(size_t)t * nbq + bq] = m;
-  }
+  // one pass: thread = one column of a 256-column strip; the column maximum of the 64 rows stays in a register, the row
+  // maxima of the strip's four 64-column blocks come from a DPP max per row and wave
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int q = qa + w; q < qb; q += 4)
-    for (int bt = 0; bt * 64 < T; ++bt) {
-      const int t = bt * 64 + lane;
-      float m = t < T ? load_score(Hbase, pd.plane_off, ld, q, t, h_mode) : NEG;
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-      if (lane == 0) rm[(size_t)q * nbt + bt] = m;
+  for (int t0 = 0; t0 < T; t0 += 256) {
+    const int t = t0 + threadIdx.x;
+    const bool in = t < T;
+    float cmaxv = NEG;
+    for (int q = qa; q < qb; ++q) {
+      const float v = in ? load_score(Hbase, pd.plane_off, ld, q, t, h_mode) : NEG;
+      cmaxv = fmaxf(cmaxv, v);
+      const float rv = wave_max_f32(v);
+      const int bt = (t0 >> 6) + w;
+      if (lane == 0 && bt * 64 < T) rm[(size_t)q * nbt + bt] = rv;
     }
+    if (in) cm[(size_t)t * nbq + bq] = cmaxv;
+  }
 }
 
 }  // namespace aln
