@@ -456,7 +456,7 @@ def main():
         assert np.array_equal(e_sc.view(np.uint32), all_sc.view(np.uint32))
         out["end_to_end"] = {"ms_per_step": round(e2e * 1e3, 3), "value": round(be.cells() / e2e / 1e9, 1), "unit": "GCUPS", "steps": n_e2e,
                              "includes": "residue encoding + H2D of codes and table, DP + corner kernels, find_max + traceback, D2H of all "
-                                         "%d pair lists, SequenceGaps strings + calcIdentity on the host (one thread); one stream, no "
+                                         "%d pair lists, SequenceGaps strings + calcIdentity on the host (up to 8 threads); one stream, no "
                                          "pipelining" % args.pairs}
         be.close()
         out["secondary"] = secondary_configs(aln_amd, c0, alphabet, table, qs, ts, args.length)

@@ -9,12 +9,13 @@
   c3    one 2000 x 2000 GLOBAL profile pair (bench_c3's generator, seeds 3000 / 4000) through oracle/_ref/ref_profile
         (real hmath.h / SimilarityMatrix / DPMatrix / Optimal): sha256 of S, H, PQ, PT + Optimal.
   long  four pairs between 2049 and 4094 residues (the kernels' paths beyond 2048 columns / rows): plane sha256 + Optimal.
+  c2ucw UnconstrainedNearOptimal sets of three of the c2 homologs (added to their c2 entries; needs the c2 part in the file).
   longm four more such pairs in the non-local align_t (global, global-local, semi-local, mode 0).
   c5    a 32 x 32 block of config 5's sequence set (seed 5000+s, 400..600 aa): the score Optimal reports, local 11/1;
         and 12 x 12 blocks for the other four align_t.
 
 The O(n^3) reference needs ~25-40 s per 2000 x 2000 pair and core; everything runs once, in parallel, here.
-usage: gen_golden_full.py [c2] [c3] [c5] [long] [longm]   (default: all; parts not regenerated are kept from the existing file)
+usage: gen_golden_full.py [c2] [c3] [c5] [long] [longm] [c2ucw]   (default: all; parts not regenerated are kept from the existing file)
 """
 import hashlib
 import json
@@ -108,6 +109,22 @@ def run_c4(p, delta):
         return p, delta, None
     s = refrun.parse(pr.stdout)["sets"]["CW"]
     print("c4 pair %d delta %g: %d alignments" % (p, delta, s["n"]), flush=True)
+    return p, delta, compact_set(s)
+
+
+C4_UCW = [(1, 0.002), (3, 0.002), (513, 0.002)]    # UnconstrainedNearOptimal at full size: DELTA_RATIOs the reference finishes in ~1 min
+
+
+def run_ucw(p, delta):
+    """UnconstrainedNearOptimal (ucw.h:64-236) on a config-2 homolog at K=256: the sorted set, or None (out of memory)."""
+    q, t = c2_pair(p)
+    cmd = "ulimit -v %d; exec %s aa %s 3 11.0 1.0 fwd %s %s ucw 256 %r" % (2 * C4_MEM_KB, refrun.HARNESS, refrun.BLOSUM62, q, t, delta)
+    pr = subprocess.run(["/bin/bash", "-c", cmd], capture_output=True, text=True)
+    if pr.returncode != 0:
+        print("ucw pair %d delta %g: reference did not finish (rc %d)" % (p, delta, pr.returncode), flush=True)
+        return p, delta, None
+    s = refrun.parse(pr.stdout)["sets"]["UCW"]
+    print("ucw pair %d delta %g: %d alignments" % (p, delta, s["n"]), flush=True)
     return p, delta, compact_set(s)
 
 
@@ -227,7 +244,7 @@ LONGM_CASES = [("g2100", 2110, 2100, 2060, True, 1), ("gl2300", 2111, 2300, 2049
 def main():
     if not refrun.available():
         raise SystemExit("oracle/_ref/ref_harness missing: run `make -C oracle` where /root/reference exists")
-    parts = [a for a in sys.argv[1:] if a in ("c2", "c3", "c5", "long", "longm")] or ["c2", "c3", "c5", "long", "longm"]
+    parts = [a for a in sys.argv[1:] if a in ("c2", "c3", "c5", "long", "longm", "c2ucw")] or ["c2", "c3", "c5", "long", "longm", "c2ucw"]
     doc = {"generator": "oracle/gen_golden_full.py via oracle/_ref (real reference, g++ -O2, no -ffast-math)"}
     if os.path.exists(OUT):
         with open(OUT) as f:
@@ -245,6 +262,10 @@ def main():
         if futl:
             doc["long"] = {"note": "pairs beyond the 2048-residue limit of the 11-bit tag layout, local 11/1 BLOSUM62; homologs truncated to "
                                    "(qlen, tlen)", "pairs": [f.result() for f in futl]}
+        if "c2ucw" in parts:
+            by = {c["pair"]: c for c in doc["c2"]["pairs"]}
+            for p, d, st in pool.map(lambda a: run_ucw(*a), C4_UCW):
+                by[p].setdefault("ucw", {})["%g" % d] = st
         if futm:
             doc["longm"] = {"note": "pairs beyond 2048 residues in the non-local align_t (mode field), 11/1 BLOSUM62", "pairs": [f.result() for f in futm]}
     with open(OUT, "w") as f:

@@ -317,3 +317,33 @@ def test_non_local_pairs_beyond_2048_residues_equal_the_reference(kernel, blosum
         check_planes(b, 0, g, "%s %s" % (kn, g["name"]))
         check_opt(g, scores[0], lists[0], "%s %s" % (kn, g["name"]))
         b.close()
+
+
+@pytest.mark.parametrize("waves", [0, 1], ids=["waves_auto", "one_wave"])
+def test_c4_unconstrained_sets_at_full_size(waves, blosum62):
+    """Config 4's other enumerator ("both cw and ucw"): UnconstrainedNearOptimal, NUM_SUBOPT=256, on three of the pinned
+    2000 x 2000 homologs at the DELTA_RATIO the reference finishes in about a minute per pair (0.002) — the sets (scores, pair
+    lists, identities, gapped strings) against the reference's, from both search kernels."""
+    alpha, table = blosum62
+    gold = [g for g in doc()["c2"]["pairs"] if g.get("ucw")]
+    if not gold:
+        pytest.skip("tests/golden/full_cases.json holds no ucw sets")
+    pr = [c2_pair(g["pair"]) for g in gold]
+    ctx = gpu_util.ctx()
+    b = aln_amd.Batch(ctx, [p[0] for p in pr], [p[1] for p in pr])
+    b.dp_submatrix(alpha, table, aln_amd.LOCAL, 11, 1, aln_amd.FWD, aln_amd.DP_FAST)
+    with ctx.hints(enum_waves=waves):
+        for k, g in enumerate(gold):
+            for delta_key, ref in g["ucw"].items():
+                if ref is None:
+                    continue
+                got = b.enumerate(k, "ucw", 256, float(delta_key), max_alignments=258)
+                n = len(got)
+                lengths = np.array([len(e["pairs"]) for e in got], dtype=np.int32)
+                stride = int(lengths.max())
+                pairs = np.zeros((n, stride, 2), dtype=np.int32)
+                for a, e in enumerate(got):
+                    pairs[a, :lengths[a]] = e["pairs"]
+                scores = np.array([e["score"] for e in got], dtype=np.float32)
+                _check_cw_set({"cw": {delta_key: ref}}, delta_key, pr[k][0], pr[k][1], n, scores, lengths, pairs, "ucw %s pair %d" % (delta_key, g["pair"]))
+    b.close()
