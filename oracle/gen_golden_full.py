@@ -9,13 +9,14 @@
   c3    one 2000 x 2000 GLOBAL profile pair (bench_c3's generator, seeds 3000 / 4000) through oracle/_ref/ref_profile
         (real hmath.h / SimilarityMatrix / DPMatrix / Optimal): sha256 of S, H, PQ, PT + Optimal.
   long  four pairs between 2049 and 4094 residues (the kernels' paths beyond 2048 columns / rows): plane sha256 + Optimal.
+  c3sl  a second 2000 x 2000 profile pair, semi_local.
   c2ucw UnconstrainedNearOptimal sets of three of the c2 homologs (added to their c2 entries; needs the c2 part in the file).
   longm four more such pairs in the non-local align_t (global, global-local, semi-local, mode 0).
   c5    a 32 x 32 block of config 5's sequence set (seed 5000+s, 400..600 aa): the score Optimal reports, local 11/1;
         and 12 x 12 blocks for the other four align_t.
 
 The O(n^3) reference needs ~25-40 s per 2000 x 2000 pair and core; everything runs once, in parallel, here.
-usage: gen_golden_full.py [c2] [c3] [c5] [long] [longm] [c2ucw]   (default: all; parts not regenerated are kept from the existing file)
+usage: gen_golden_full.py [c2] [c3] [c5] [long] [longm] [c2ucw] [c3sl]   (default: all; parts not regenerated are kept from the existing file)
 """
 import hashlib
 import json
@@ -139,25 +140,21 @@ def gen_c2(pool):
             "flags": "".join(str(int(x)) for x in make_subopt_regions(C2_LEN + 2, 10)), "pairs": cases}
 
 
-def gen_c3():
+def gen_c3(mode=1, q_seed=3000, t_seed=4000):
     L = 2000
-    qp, tp = random_profile(3000, L), random_profile(4000, L)
+    qp, tp = random_profile(q_seed, L), random_profile(t_seed, L)
     os.makedirs(TMP, exist_ok=True)
-    path = os.path.join(TMP, "c3.bin")
-    os.environ["REF_PROFILE_BIN"] = path
-    try:
-        r = refrun.run_profile(qp, tp, 1, 0.5, 1.0, 0.12, 4.73, 0.34, 1, timeout=7200)
-    finally:
-        del os.environ["REF_PROFILE_BIN"]
+    path = os.path.join(TMP, "c3_%d.bin" % mode)
+    r = refrun.run_profile(qp, tp, mode, 0.5, 1.0, 0.12, 4.73, 0.34, 1, timeout=7200, env={"REF_PROFILE_BIN": path})
     raw = np.fromfile(path, dtype=np.int32)
     os.remove(path)
     Q, T = int(raw[0]), int(raw[1])
     pl = raw[2:].reshape(4, Q, T)
     opt = r["sets"]["OPT"]["alis"][0]
-    print("c3: opt score %g (%d pairs)" % (float(opt["score"]), len(opt["pairs"])), flush=True)
-    return {"note": "bench_c3 pair 0 (random_profile(3000, 2000) x random_profile(4000, 2000)), global, alpha 0.5 beta 1 zero_shift 0.12, "
-                    "gaps 4.73/0.34, through oracle/_ref/ref_profile",
-            "len": L, "q_seed": 3000, "t_seed": 4000, "mode": 1, "alpha": 0.5, "beta": 1.0, "zero_shift": 0.12, "gi": 4.73, "ge": 0.34,
+    print("c3 mode %d: opt score %g (%d pairs)" % (mode, float(opt["score"]), len(opt["pairs"])), flush=True)
+    return {"note": "random_profile(%d, 2000) x random_profile(%d, 2000) (bench_c3 pair 0 for 3000/4000), align_t %d, alpha 0.5 beta 1 zero_shift 0.12, "
+                    "gaps 4.73/0.34, through oracle/_ref/ref_profile" % (q_seed, t_seed, mode),
+            "len": L, "q_seed": q_seed, "t_seed": t_seed, "mode": mode, "alpha": 0.5, "beta": 1.0, "zero_shift": 0.12, "gi": 4.73, "ge": 0.34,
             "sha": {"S": sha(pl[0].view(np.uint32)), "H": sha(pl[1].view(np.uint32)), "PQ": sha(pl[2]), "PT": sha(pl[3])},
             "row_crc": {"S": row_crc(pl[0]), "H": row_crc(pl[1]), "P": row_crc(np.stack([pl[2], pl[3]], axis=2))},
             "tgi_sha": sha(r["TGI"].view(np.uint32)), "tge_sha": sha(r["TGE"].view(np.uint32)),
@@ -244,7 +241,7 @@ LONGM_CASES = [("g2100", 2110, 2100, 2060, True, 1), ("gl2300", 2111, 2300, 2049
 def main():
     if not refrun.available():
         raise SystemExit("oracle/_ref/ref_harness missing: run `make -C oracle` where /root/reference exists")
-    parts = [a for a in sys.argv[1:] if a in ("c2", "c3", "c5", "long", "longm", "c2ucw")] or ["c2", "c3", "c5", "long", "longm", "c2ucw"]
+    parts = [a for a in sys.argv[1:] if a in ("c2", "c3", "c5", "long", "longm", "c2ucw", "c3sl")] or ["c2", "c3", "c5", "long", "longm", "c2ucw", "c3sl"]
     doc = {"generator": "oracle/gen_golden_full.py via oracle/_ref (real reference, g++ -O2, no -ffast-math)"}
     if os.path.exists(OUT):
         with open(OUT) as f:
@@ -262,6 +259,8 @@ def main():
         if futl:
             doc["long"] = {"note": "pairs beyond the 2048-residue limit of the 11-bit tag layout, local 11/1 BLOSUM62; homologs truncated to "
                                    "(qlen, tlen)", "pairs": [f.result() for f in futl]}
+        if "c3sl" in parts:                              # config 3 "global ... and semi_local"
+            doc["c3sl"] = pool.submit(gen_c3, 4, 3001, 4001).result()
         if "c2ucw" in parts:
             by = {c["pair"]: c for c in doc["c2"]["pairs"]}
             for p, d, st in pool.map(lambda a: run_ucw(*a), C4_UCW):

@@ -74,7 +74,7 @@ def run_sub(q, t, mode, gi, ge, direction, q1, t1, q2, t2, blosum=BLOSUM62):
     return parse(out)
 
 
-def run_profile(qp, tp, mode, alpha, beta, zero_shift, gi, ge, direction=1, timeout=600):
+def run_profile(qp, tp, mode, alpha, beta, zero_shift, gi, ge, direction=1, timeout=600, env=None):
     """qp/tp: dicts with float32 arrays aa[L,20], sse[L,3], conf[L] (sentinel rows included)."""
     def seq(p):
         L = len(p["conf"])
@@ -85,7 +85,9 @@ def run_profile(qp, tp, mode, alpha, beta, zero_shift, gi, ge, direction=1, time
             lines.append(olc + " " + " ".join("%.9g" % float(v) for v in vals))
         return "\n".join(lines)
     text = "%d %.9g %.9g %.9g %.9g %.9g %d\n%s\n%s\n" % (mode, alpha, beta, zero_shift, gi, ge, direction, seq(qp), seq(tp))
-    out = subprocess.run([PROFILE], input=text, capture_output=True, text=True, timeout=timeout, check=True).stdout
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run([PROFILE], input=text, capture_output=True, text=True, timeout=timeout, check=True, env=e).stdout
     res = parse(out)
     for line in out.split("\n"):
         tag, _, rest = line.partition(" ")

@@ -200,23 +200,32 @@ def test_random_batch_vs_oracle(mode, tag_bits, blosum62):
             q, t = residues(g, ql), residues(g, tl)
         qs.append(q)
         ts.append(t)
+    # local builds have three plane layouts (uint16 scores + the 16-bit key layout, uint16 scores with 13-/14-bit keys, fp32 scores)
+    layouts = ({}, {"key16": 0}, {"h16": 0, "key16": 0}) if mode == 3 else ({},)
     for (gi, ge) in ((11, 1), (3, 0), (0, 2)):
-        with gpu_util.ctx().hints(tag_bits=tag_bits):
-            b = aln_amd.Batch(gpu_util.ctx(), qs, ts)
-            b.dp_submatrix(alpha, table, mode, gi, ge, aln_amd.FWD, aln_amd.DP_FAST)
-        assert "dp_affine_tag" in b.kernel_name() and ("tag12" in b.kernel_name()) == (tag_bits == 12), b.kernel_name()
-        scores, lists, status = b.optimal()
-        for p, (q, t) in enumerate(zip(qs, ts)):
+        ref = []
+        for q, t in zip(qs, ts):
             S = orc.sim_submatrix(q, t, alpha, table)
             rc, D0, PQ0, PT0 = orc.dp_build(S, orc.Gap(mode, gi, ge))
-            D, PQ, PT = b.get_cells(p)
-            assert np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (p, mode, gi, ge)
-            assert np.array_equal(PQ, PQ0) and np.array_equal(PT, PT0), (p, mode, gi, ge)
-            rc2, sc, pairs = orc.optimal(D0, PQ0, PT0, mode == 3)
-            assert status[p] == rc2 == 0
-            assert np.float32(scores[p]).view(np.uint32) == sc.view(np.uint32)
-            assert np.array_equal(lists[p], pairs)
-        b.close()
+            ref.append((D0, PQ0, PT0) + tuple(orc.optimal(D0, PQ0, PT0, mode == 3)))
+        for layout in layouts:
+            with gpu_util.ctx().hints(tag_bits=tag_bits, **layout):
+                b = aln_amd.Batch(gpu_util.ctx(), qs, ts)
+                b.dp_submatrix(alpha, table, mode, gi, ge, aln_amd.FWD, aln_amd.DP_FAST)
+            kn = b.kernel_name()
+            assert "dp_affine_tag" in kn and ("tag12" in kn) == (tag_bits == 12), kn
+            if mode == 3:
+                assert ("key16" in kn) == (layout.get("key16", 1) == 1) and ("h16" in kn) == (layout.get("h16", 1) == 1), kn
+            scores, lists, status = b.optimal()
+            for p in range(len(qs)):
+                D0, PQ0, PT0, rc2, sc, pairs = ref[p]
+                D, PQ, PT = b.get_cells(p)
+                assert np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (p, mode, gi, ge, kn)
+                assert np.array_equal(PQ, PQ0) and np.array_equal(PT, PT0), (p, mode, gi, ge, kn)
+                assert status[p] == rc2 == 0
+                assert np.float32(scores[p]).view(np.uint32) == sc.view(np.uint32)
+                assert np.array_equal(lists[p], pairs)
+            b.close()
 
 
 @pytest.mark.parametrize("kernel", ["tag", "int"])

@@ -188,10 +188,14 @@ def test_c4_enumerate_all_at_full_size(waves, blosum62):
     ctx.set_hint("enum_waves", 0)
 
 
-def test_c3_profile_pair_at_full_size():
-    """Config 3: one 2000 x 2000 GLOBAL Hmap2Eval pair (bench_c3's pair 0): similarity + z-normalisation on the device, the
-    tiled exact-order kernel, Optimal — against the reference's hmath.h / SimilarityMatrix / DPMatrix / Optimal."""
-    g = doc()["c3"]
+@pytest.mark.parametrize("part", ["c3", "c3sl"])
+def test_c3_profile_pair_at_full_size(part):
+    """Config 3: one 2000 x 2000 Hmap2Eval pair — GLOBAL (bench_c3's pair 0) and SEMI_LOCAL (SURVEY 8d names both) —: similarity +
+    z-normalisation on the device, the tiled exact-order kernel, Optimal — against the reference's hmath.h / SimilarityMatrix /
+    DPMatrix / Optimal."""
+    if part not in doc():
+        pytest.skip("tests/golden/full_cases.json holds no '%s' part" % part)
+    g = doc()[part]
     L = g["len"]
     qp, tp = random_profile(g["q_seed"], L), random_profile(g["t_seed"], L)
     b = aln_amd.Batch(gpu_util.ctx(), ["A" * L], ["A" * L])
