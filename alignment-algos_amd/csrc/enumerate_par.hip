@@ -43,7 +43,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
     const size_t bi = blockIdx.x;
     pair = a.pair_list ? a.pair_list[bi] : pair + (int)bi;
     a.head += bi * a.ali_cap; a.score += bi * a.ali_cap;
-    {                                                                 // node pool of this workgroup (shared with every n_pools-th pair)
+    {                                                                 // node pool of this workgroup (enum_pool_of scatters the pairs over the pools)
       const size_t pool = enum_pool_of((uint32_t)bi, a.n_pools);
       a.node_pair += pool * (size_t)a.n_chunks * kChunkNodes; a.node_next += pool * (size_t)a.n_chunks * kChunkNodes;
       a.chunk_next += pool;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
   }
   const PairDesc pd = pairs[pair];
   const int Q = pd.Q, T = pd.T, ld = pd.ld;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, W = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const bool cw = a.kind == ALN_ENUM_CW;
 
   // ---- per-pair constants into LDS: flags | template codes | query codes | 32 x 32 table -----------------------------------
