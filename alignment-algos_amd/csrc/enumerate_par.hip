@@ -93,6 +93,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
   { float alt = top - 0.1f; thr = (alt < thr) ? alt : thr; }
 
   const uint32_t qcap = a.ali_cap;                    // ring of task records (every pending task owns a distinct slot, so <= ali_cap pend)
+  const uint32_t qmargin = qcap / 4u < 2048u ? qcap / 4u : 2048u;
   if (threadIdx.x == 0) {
     s_head = 0; s_tail = 1; s_done = 0; s_status = 0; s_nodes = 0u; s_lock = 0;
     s_slots = (unsigned)a.first_slot + 1u;             // as.push_back(SingleAlignment())  cw.h:82 / ucw.h:78
@@ -278,7 +279,9 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
         bt = (uint32_t)__shfl((int)bt, 0); bs = (uint32_t)__shfl((int)bs, 0);
         if (nnew && bs + (uint32_t)nnew > a.user_limit) { fail(kParSerial); dead = true; return; }   // the serial order decides what user_limit cuts
         const uint32_t pending = bt + (uint32_t)n - (uint32_t)__hip_atomic_load(&s_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (pending + 64u > qcap || bs + (uint32_t)nnew > a.ali_cap) {
+        // (every wave of the workgroup may be pushing 64 records at this moment: keep that much of the ring free, so that no
+        // record is overwritten before the wave that took its ticket has read it)
+        if (pending + qmargin > qcap || bs + (uint32_t)nnew > a.ali_cap) {
           fail(ALN_E_OVERFLOW); dead = true; return;
         }
         if ((m >> lane) & 1ull) {
