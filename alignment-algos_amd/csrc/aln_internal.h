@@ -143,7 +143,7 @@ struct aln_batch {
   // device pools of aln_batch_enumerate_all, kept between calls (hint enum_keep_pools): a hipMalloc of tens of GB costs seconds
   uint8_t* h_stage_pin = nullptr; size_t h_stage_bytes = 0;   // pinned staging of residue codes + table (upload_submatrix)
   struct Scratch { void* p = nullptr; size_t bytes = 0; };
-  Scratch enum_scratch[8];
+  Scratch enum_scratch[9];
   std::vector<int32_t> enum_usage;                    // ... and what every pair's search used of its pools
   // aln_batch_optimal_enqueue / _collect: two pinned result slots
   aln::PairResult* h_slot[2] = {nullptr, nullptr};

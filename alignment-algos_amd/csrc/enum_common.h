@@ -19,6 +19,8 @@ struct EnumArgs {
   int first_slot;       // index of the enumerator's seed alignment inside the set (what is already there stays)
   // pools (for this pair)
   uint32_t* node_pair; uint32_t* node_next; uint32_t node_cap;
+  uint8_t* node_len;    // enumerate_par.hip: a node is a RUN of node_len cells down the diagonal from node_pair's cell (list order: the
+                        // run's far end first); nullptr: every node is one cell (the one-wave kernels)
   uint32_t* head; float* score; uint32_t ali_cap;
   uint32_t* stack; uint32_t stack_cap;   // frames of kFrameWords words
   const uint8_t* flags; // T bytes
@@ -53,6 +55,28 @@ struct EnumArgs {
 };
 
 constexpr uint32_t kNoNode = 0xFFFFFFFFu;
+
+// One alignment out of the trie, in list order (head -> end), by one wave: a node is one cell, or (node_len != nullptr) a run of
+// node_len[node] diagonal cells ending at node_pair[node]'s cell, whose cells the lanes write together.  -> list length, or -1
+// when it exceeds `stride`.  o may be nullptr (count only).
+__device__ __forceinline__ int unroll_alignment(const uint32_t* __restrict__ node_pair, const uint32_t* __restrict__ node_next,
+                                                const uint8_t* __restrict__ node_len, uint32_t node, int32_t* __restrict__ o, int stride) {
+  const int lane = threadIdx.x & 63;
+  int n = 0;
+  while (node != kNoNode) {
+    const uint32_t w = node_pair[node];
+    const int len = node_len ? (int)node_len[node] : 1;
+    if (n + len > stride) return -1;
+    if (o && lane < len) {
+      const int back = len - 1 - lane;                       // ascending cells: the run's far end (smallest indices) first
+      o[2 * (n + lane)] = (int32_t)(w >> 16) - back;
+      o[2 * (n + lane) + 1] = (int32_t)(w & 0xFFFFu) - back;
+    }
+    n += len;
+    node = node_next[node];
+  }
+  return n;
+}
 
 // All mutable pool words are accessed with agent-scope (L2-served) loads/stores: lane 0 writes, every lane reads.
 __device__ __forceinline__ uint32_t ld_u(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -284,22 +284,15 @@ __global__ __launch_bounds__(64) void enumerate_kernel(const PairDesc* __restric
   if (lane == 0) { a.out[0] = (int32_t)n_as; a.out[1] = (int32_t)n_nodes; a.out[2] = status; }
 }
 
-// unroll selected alignments: one wave per alignment, lane 0 walks the trie (list order = head -> end)
+// unroll selected alignments: one wave per alignment walks the trie (list order = head -> end)
 __global__ __launch_bounds__(64) void enum_unroll_kernel(const uint32_t* __restrict__ node_pair, const uint32_t* __restrict__ node_next,
+                                                         const uint8_t* __restrict__ node_len,
                                                          const uint32_t* __restrict__ head, const int32_t* __restrict__ sel, int nsel,
                                                          int32_t* __restrict__ out_pairs, int32_t* __restrict__ out_n, int stride) {
   const int s = blockIdx.x;
-  if (s >= nsel || threadIdx.x != 0) return;
-  uint32_t node = head[sel[s]];
-  int n = 0;
-  int32_t* o = out_pairs + (size_t)s * stride * 2;
-  while (node != kNoNode && n < stride) {
-    uint32_t p = node_pair[node];
-    o[2 * n] = (int32_t)(p >> 16); o[2 * n + 1] = (int32_t)(p & 0xFFFFu);
-    ++n;
-    node = node_next[node];
-  }
-  out_n[s] = (node == kNoNode) ? n : -1;
+  if (s >= nsel) return;
+  const int n = unroll_alignment(node_pair, node_next, node_len, head[sel[s]], out_pairs + (size_t)s * stride * 2, stride);
+  if (threadIdx.x == 0) out_n[s] = n;
 }
 
 }  // namespace aln
@@ -464,7 +457,7 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   uint8_t* d_flags = nullptr; int32_t* d_out = nullptr;
   auto cleanup = [&]() {
     hipFree(a.node_pair); hipFree(a.node_next); hipFree(a.head); hipFree(a.score); hipFree(a.stack); hipFree(a.uid);
-    hipFree(a.cr_ali); hipFree(a.cr_reg); hipFree(a.task); hipFree(a.slot_info); hipFree(a.chunk_next);
+    hipFree(a.cr_ali); hipFree(a.cr_reg); hipFree(a.task); hipFree(a.slot_info); hipFree(a.chunk_next); hipFree(a.node_len);
     hipFree((void*)a.rowmax); hipFree((void*)a.colmax);
     hipFree(d_flags); hipFree(d_out);
   };
@@ -479,6 +472,7 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
     ETRY(hipMalloc((void**)&a.task, (size_t)a.ali_cap * kTaskWords * 4));
     ETRY(hipMemsetAsync(a.task, 0, (size_t)a.ali_cap * kTaskWords * 4, ctx->stream));      // ready words: ticket + 1, never 0
     ETRY(hipMalloc((void**)&a.slot_info, (size_t)a.ali_cap * 12));
+    ETRY(hipMalloc((void**)&a.node_len, (size_t)a.node_cap));
     a.n_chunks = a.node_cap / kChunkNodes;              // (node_cap was rounded to chunks above)
     a.n_pools = 1;
     ETRY(hipMalloc((void**)&a.chunk_next, 4));
@@ -585,7 +579,8 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
     bool okk = e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess;
     if (okk) okk = hipMemcpyAsync(d_sel, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
     if (okk) {
-      hipLaunchKernelGGL(enum_unroll_kernel, dim3((unsigned)sel.size()), dim3(64), 0, ctx->stream, a.node_pair, a.node_next, a.head,
+      hipLaunchKernelGGL(enum_unroll_kernel, dim3((unsigned)sel.size()), dim3(64), 0, ctx->stream, a.node_pair, a.node_next,
+                         used_par ? a.node_len : (const uint8_t*)nullptr, a.head,
                          d_sel, (int)sel.size(), d_lists, d_lens, stride);
       okk = hipGetLastError() == hipSuccess;
     }
@@ -638,6 +633,7 @@ namespace aln {
 // one wave per (pair, slot): slot's alignment index comes from sel[]; -1 = empty, 0 = the pair's Optimal alignment
 // (taken from the traceback list, which is stored end -> start), otherwise a trie walk.
 __global__ __launch_bounds__(64) void enum_unroll_all_kernel(const uint32_t* __restrict__ node_pair, const uint32_t* __restrict__ node_next,
+                                                             const uint8_t* __restrict__ node_len,
                                                              const uint32_t* __restrict__ head, size_t node_stride, int n_pools, uint32_t ali_cap,
                                                              const int32_t* __restrict__ sel, int K, const int32_t* __restrict__ pair_list,
                                                              const int32_t* __restrict__ path,
@@ -656,19 +652,11 @@ __global__ __launch_bounds__(64) void enum_unroll_all_kernel(const uint32_t* __r
     if (threadIdx.x == 0) out_n[(size_t)p * K + k] = n;
     return;
   }
-  if (threadIdx.x != 0) return;
   // a slice per pair (one-wave kernels: n_pools = 0) or the pool workgroup p of enumerate_par.hip used (enum_pool_of)
   const size_t nbase = n_pools ? (size_t)enum_pool_of((uint32_t)p, (uint32_t)n_pools) * node_stride : (size_t)p * node_stride;
-  const uint32_t* np_ = node_pair + nbase;
-  const uint32_t* nn_ = node_next + nbase;
-  uint32_t node = head[(size_t)p * ali_cap + idx];
-  int n = 0;
-  while (node != kNoNode && n < stride) {
-    if (o) { uint32_t w = np_[node]; o[2 * n] = (int32_t)(w >> 16); o[2 * n + 1] = (int32_t)(w & 0xFFFFu); }
-    ++n;
-    node = nn_[node];
-  }
-  out_n[(size_t)p * K + k] = (node == kNoNode) ? n : -1;
+  const int n = unroll_alignment(node_pair + nbase, node_next + nbase, node_len ? node_len + nbase : nullptr,
+                                 head[(size_t)p * ali_cap + idx], o, stride);
+  if (threadIdx.x == 0) out_n[(size_t)p * K + k] = n;
 }
 }  // namespace aln
 
@@ -729,7 +717,7 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
     hipFree(a.cr_ali); hipFree(a.cr_reg); hipFree(a.chunk_next);
     hipFree(d_out); hipFree(d_sel); hipFree(d_lens); hipFree(d_list);
     a.node_pair = a.node_next = a.head = nullptr; a.score = nullptr; a.stack = nullptr; a.uid = nullptr; a.cr_ali = nullptr; a.cr_reg = nullptr;
-    a.task = a.slot_info = a.chunk_next = nullptr;
+    a.task = a.slot_info = a.chunk_next = nullptr; a.node_len = nullptr;
     d_out = d_sel = d_lists = d_lens = d_list = nullptr;
   };
   auto cleanup = [&]() {
@@ -810,6 +798,7 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
     }
     BTRY(scratch(0, pool_nodes * 4, (void**)&a.node_pair));
     BTRY(scratch(1, pool_nodes * 4, (void**)&a.node_next));
+    if (pw) BTRY(scratch(8, pool_nodes, (void**)&a.node_len));
     BTRY(scratch(2, (size_t)gn * a.ali_cap * 4, (void**)&a.head));
     BTRY(scratch(3, (size_t)gn * a.ali_cap * 4, (void**)&a.score));
     if (pw) {
@@ -933,7 +922,8 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
     if (pairs) BTRY(scratch(6, sel.size() * (size_t)pair_stride * 8, (void**)&d_lists));
     BTRY(hipMemcpyAsync(d_sel, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     BTRY(hipEventRecord(evs[2], ctx->stream));
-    hipLaunchKernelGGL(enum_unroll_all_kernel, dim3(K, gn), dim3(64), 0, ctx->stream, a.node_pair, a.node_next, a.head,
+    hipLaunchKernelGGL(enum_unroll_all_kernel, dim3(K, gn), dim3(64), 0, ctx->stream, a.node_pair, a.node_next,
+                       pw ? a.node_len : (const uint8_t*)nullptr, a.head,
                        pw ? (size_t)a.n_chunks * kChunkNodes : (size_t)a.node_cap, pw ? (int)a.n_pools : 0, a.ali_cap,
                        d_sel, K, d_list, b->d_path, b->path_stride, b->d_res, d_lists, d_lens, pairs ? pair_stride : (1 << 30));
     BTRY(hipGetLastError());

@@ -46,6 +46,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
     {                                                                 // node pool of this workgroup (enum_pool_of scatters the pairs over the pools)
       const size_t pool = enum_pool_of((uint32_t)bi, a.n_pools);
       a.node_pair += pool * (size_t)a.n_chunks * kChunkNodes; a.node_next += pool * (size_t)a.n_chunks * kChunkNodes;
+      a.node_len += pool * (size_t)a.n_chunks * kChunkNodes;
       a.chunk_next += pool;
     }
     a.task += bi * (size_t)a.ali_cap * kTaskWords;
@@ -202,8 +203,8 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
       const uint32_t b = take_nodes(2);
       if (b == kNoNode) return;
       if (lane == 0) {
-        a.node_pair[b] = ((uint32_t)q0 << 16) | (uint32_t)t0; a.node_next[b] = hd;
-        a.node_pair[b + 1] = 0u; a.node_next[b + 1] = b;
+        a.node_pair[b] = ((uint32_t)q0 << 16) | (uint32_t)t0; a.node_next[b] = hd; a.node_len[b] = 1;
+        a.node_pair[b + 1] = 0u; a.node_next[b + 1] = b; a.node_len[b + 1] = 1;
         a.head[slot] = b + 1;
         a.score[slot] = sc + HV(q0, t0);
       }
@@ -232,13 +233,10 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
           const bool gap_cell = F < 64 && !(((__ballot(stop)) >> F) & 1ull);
           const int n_proc = gap_cell ? F + 1 : F;
           if (n_proc == 0) break;
-          const uint32_t b = take_nodes(n_proc);
+          const uint32_t b = take_nodes(1);              // ONE trie node for the run of n_proc diagonal cells from (q0,t0) down
           if (b == kNoNode) { dead = true; break; }
-          if (lane < n_proc) {
-            a.node_pair[b + lane] = ((uint32_t)q << 16) | (uint32_t)t;
-            a.node_next[b + lane] = lane == 0 ? hd : b + lane - 1;
-          }
-          hd = b + n_proc - 1;
+          if (lane == 0) { a.node_pair[b] = ((uint32_t)q << 16) | (uint32_t)t; a.node_next[b] = hd; a.node_len[b] = (uint8_t)n_proc; }
+          hd = b;
           if (gap_cell && lane == F) {
             if (q - pq == 1) g = dev_deletion(e, pt, t);
             else g = dev_insertion(e, pq, q, pt, t);
@@ -289,6 +287,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
           const uint32_t nd = bn + (uint32_t)rnk;
           a.node_pair[nd] = ((uint32_t)q0 << 16) | (uint32_t)t0;
           a.node_next[nd] = hd;
+          a.node_len[nd] = 1;
           const int srank = rnk - (first ? 1 : 0);
           uint32_t sl = slot;
           if (srank >= 0) {

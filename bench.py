@@ -135,7 +135,7 @@ def secondary_configs(aln_amd, ctx, alphabet, table, qs, ts, length):
     best = first = None
     for rep in range(2):
         t0 = time.perf_counter()
-        n_out, scores, lengths, _, status = b.enumerate_all("cw", 256, 0.01, flags, K=258, node_cap=1 << 22, ali_cap=1 << 16,
+        n_out, scores, lengths, _, status = b.enumerate_all("cw", 256, 0.01, flags, K=258, node_cap=1 << 18, ali_cap=1 << 16,
                                                             want_pairs=False, raise_on_overflow=False)
         dt = time.perf_counter() - t0
         first = dt if first is None else first

@@ -35,7 +35,7 @@ def main():
     flags = make_subopt_regions(L + 2, regions)
     for rep in range(2):
         t0 = time.perf_counter()
-        n_out, scores, lengths, lists, status = b.enumerate_all(kind, K, delta, flags, K=K + 2, node_cap=int(os.environ.get("NODE_CAP", 1 << 23)),
+        n_out, scores, lengths, lists, status = b.enumerate_all(kind, K, delta, flags, K=K + 2, node_cap=int(os.environ.get("NODE_CAP", 1 << 19)),
                                                                ali_cap=int(os.environ.get("ALI_CAP", 1 << 16)), want_pairs=(rep == 1),
                                                                raise_on_overflow=False)
         t1 = time.perf_counter()
