@@ -274,12 +274,15 @@ int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* noa, const ui
                         int32_t* pairs, int64_t pairs_capacity, int32_t* n_out);
 
 /* The same enumeration for EVERY pair of the resident batch in one launch (BASELINE config 4: top-K near-optimal
- * tracebacks per pair from the GPU-resident matrices): one wave per pair walks its own search, the host runs
- * sortSet(number_suboptimal) per pair on (score, index) keys, survivors are unrolled on the device.  Every set is
- * seeded with the pair's Optimal alignment (noa->n_existing is ignored).
+ * tracebacks per pair from the GPU-resident matrices): one workgroup per pair runs its search (cw / ucw: 16 waves share it,
+ * csrc/enumerate_par.hip; the pruned enumerators: one wave), the host runs sortSet(number_suboptimal) per pair on (score,
+ * index) keys in the reference's set order, survivors are unrolled on the device.  Every set is seeded with the pair's Optimal
+ * alignment (noa->n_existing is ignored).
  *   flags: SuboptFlags rows, pair p's row at flags + p * flags_stride (flags_stride 0: one shared row of max T bytes);
  *   node_cap_per_pair / ali_cap_per_pair: trie nodes / alignments one pair's pools hold at first (0 = 1 Mi nodes / 64 Ki
- *   alignments); pairs that need more are searched again with 4 x larger pools, in groups sized to a device-memory budget,
+ *   alignments).  A trie node is one aligned pair for the one-wave kernels and one diagonal run of up to 64 aligned pairs for
+ *   the several-wave kernel, whose node pool is moreover shared by the pairs of a launch (n_pairs x node_cap_per_pair nodes in
+ *   all: a 2000-residue homolog at DELTA_RATIO 0.01 needs 0.03-0.8 M of them).  Pairs that need more are searched again with 4 x larger pools, in groups sized to a device-memory budget,
  *   "enum_pool_retries" times (context hint, default 2), and only then report ALN_E_OVERFLOW;  K: slots per pair in the outputs (>= min(number_suboptimal, set size)).
  * Outputs (slot k of pair p at index p*K + k, set order): n_out[p] = set size after sortSet, scores, lengths,
  * pairs (NULL = not wanted) as (q,t) int32 at (p*K + k) * pair_stride * 2, status[p] = 0 / ALN_E_STARTPAIR /
@@ -289,7 +292,7 @@ int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const uint8_t* fla
                             int32_t* n_out, float* scores, int32_t* lengths, int32_t* pairs, int32_t pair_stride,
                             int32_t* status);
 /* What the last aln_batch_enumerate_all used of every pair's pools: alignments created before sortSet (the reference's
- * as.size(), cw.h:91) and trie nodes — also for pairs that reported ALN_E_OVERFLOW (the count at which they stopped), so that a
+ * as.size(), cw.h:91) and trie nodes (the several-wave kernel: runs, reserved 512 at a time by each wave) — also for pairs that reported ALN_E_OVERFLOW (the count at which they stopped), so that a
  * caller can size node_cap_per_pair / ali_cap_per_pair.  Either pointer may be NULL. */
 int aln_batch_last_enum_usage(aln_batch* b, int32_t* alignments, int32_t* nodes);
 /* Milliseconds the device spent in the search kernel / the unroll kernel of the last aln_batch_enumerate_all. */
