@@ -492,7 +492,7 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   a.int_sums = b->ptr_mode != 0;
   a.out = d_out;
   float *d_bmr = nullptr, *d_bmc = nullptr;
-  if (pw) { int rcb = make_blockmax(b, a, pair, 1, &d_bmr, &d_bmc); if (rcb) { cleanup(); return rcb; } }
+  if (pw || noa->kind == ALN_ENUM_KSCW) { int rcb = make_blockmax(b, a, pair, 1, &d_bmr, &d_bmc); if (rcb) { cleanup(); return rcb; } }
 
   EvalDev proto = {};
   proto.model = b->gapdev.model; proto.align_type = b->gapdev.align_type;
@@ -745,7 +745,7 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   BTRY(hipStreamSynchronize(ctx->stream));
   b->enum_usage.assign((size_t)n * 4, 0);
   b->enum_search_ms = b->enum_unroll_ms = 0.f;
-  if (par_waves(b, noa->kind, n)) {                      // block maxima of every pair's score plane, once (the pruned scan of enumerate_par.hip)
+  if (par_waves(b, noa->kind, n) || noa->kind == ALN_ENUM_KSCW) {   // block maxima of every pair's score plane, once (the pruned scans of enumerate_par.hip / enumerate_ks.hip)
     int rcb = make_blockmax(b, a0, 0, n, &d_bmr, &d_bmc);
     if (rcb) { cleanup(); return rcb; }
   }

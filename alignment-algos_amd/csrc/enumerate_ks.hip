@@ -152,6 +152,54 @@ __global__ __launch_bounds__(64) void enumerate_ks_kernel(const PairDesc* __rest
       const int ndel = t0 - 2, nins = q0 - 2;
       const int ncand = 1 + ndel + nins;
       int n = 0;
+      // one 64-candidate group: the lanes that pass append (sum, candidate index) to the LDS arrays in lane order
+      auto collect = [&](bool ok, float sum, int idx) {
+        const unsigned long long m = __ballot(ok);
+        if (m) {
+          const int pos = n + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+          if (ok && pos < (int)a.cand_cap) { csc[pos] = sum; cix[pos] = idx; }
+          n += __builtin_popcountll(m);
+        }
+      };
+      if (e.model == ALN_GAP_AFFINE_CONST && a.rowmax && Q <= 4096 && T <= 4096 && e.gi >= 0.f && e.ge >= 0.f) {
+        // pruned scan (see enumerate_par.hip): only the 64-cell blocks of the candidate row / column whose maximum can pass are read
+        const bool fdel = (e.align_type == ALN_LOCAL || e.align_type == ALN_SEMI_LOCAL || e.align_type == ALN_LOCAL_GLOBAL);
+        const bool fins = (e.align_type == ALN_LOCAL || e.align_type == ALN_SEMI_LOCAL || e.align_type == ALN_GLOBAL_LOCAL);
+        const float* rmax = a.rowmax + ((size_t)(pair - a.bm_pair0) * a.bm_rows + (size_t)(q0 - 1)) * a.nbt;
+        const float* cmax = a.colmax + ((size_t)(pair - a.bm_pair0) * a.bm_cols + (size_t)(t0 - 1)) * a.nbq;
+        bool pass_d = false, pass_i = false;
+        {
+          const int lo = lane * 64 > 1 ? lane * 64 : 1;
+          int hi = lane * 64 + 63; hi = hi < t0 - 2 ? hi : t0 - 2;
+          if (lo <= hi) {
+            const int len = t0 - hi - 1;
+            const float g = (len < 1 || (fdel && t0 == T - 1)) ? 0.f : e.gi + e.ge * (float)(len - 1);
+            pass_d = (rmax[lane] + r) - g > thr;
+          }
+          int hq = lane * 64 + 63; hq = hq < q0 - 2 ? hq : q0 - 2;
+          if (lo <= hq) {
+            const int len = q0 - hq - 1;
+            const float g = (len < 1 || (fins && q0 == Q - 1)) ? 0.f : e.gi + e.ge * (float)(len - 1);
+            pass_i = (cmax[lane] + r) - g > thr;
+          }
+        }
+        const unsigned long long md = __ballot(pass_d), mi = __ballot(pass_i);
+        collect(lane == 0 && HV(q0 - 1, t0 - 1) + r > thr, HV(q0 - 1, t0 - 1) + r, 0);                     // the match
+        for (unsigned long long mm = md; mm; ) {                                                           // deletions, t0-2 downwards
+          const int blk = 63 - __builtin_clzll(mm); mm &= ~(1ull << blk);
+          const int pt = blk * 64 + 63 - lane;
+          const bool in = pt >= 1 && pt <= t0 - 2;
+          const float sum = in ? HV(q0 - 1, pt) + r - dev_deletion(e, pt, t0) : 0.f;
+          collect(in && sum > thr, sum, t0 - 1 - pt);
+        }
+        for (unsigned long long mm = mi; mm; ) {                                                           // insertions, q0-2 downwards
+          const int blk = 63 - __builtin_clzll(mm); mm &= ~(1ull << blk);
+          const int pq = blk * 64 + 63 - lane;
+          const bool in = pq >= 1 && pq <= q0 - 2;
+          const float sum = in ? HV(pq, t0 - 1) + r - dev_insertion(e, pq, q0, t0 - 1, t0) : 0.f;
+          collect(in && sum > thr, sum, ndel + 1 + (q0 - 2 - pq));
+        }
+      } else
       for (int base = 0; base < ncand; base += 64) {
         const int idx = base + lane;
         bool ok = false; float sum = 0.f;
@@ -161,12 +209,7 @@ __global__ __launch_bounds__(64) void enumerate_ks_kernel(const PairDesc* __rest
           else { const int pq = q0 - 2 - (idx - ndel - 1); sum = HV(pq, t0 - 1) + r - dev_insertion(e, pq, q0, t0 - 1, t0); }
           ok = sum > thr;
         }
-        const unsigned long long m = __ballot(ok);
-        if (m) {
-          const int pos = n + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-          if (ok && pos < (int)a.cand_cap) { csc[pos] = sum; cix[pos] = idx; }
-          n += __builtin_popcountll(m);
-        }
+        collect(ok, sum, idx);
       }
       if (n > (int)a.cand_cap) { status = ALN_E_OVERFLOW; break; }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
