@@ -348,12 +348,14 @@ size_t cr_lds_bytes(const EnumArgs& a) { return (size_t)a.cand_cap * 8 + (size_t
 
 // ---- the several-waves-per-pair search (enumerate_par.hip) -------------------------------------------------------------
 // LDS of one workgroup: flags + template codes + query codes (16-byte padded) + the 32 x 32 table
-size_t par_lds_bytes(int maxQ, int maxT) { return (size_t)((maxT + 15) & ~15) * 2 + (size_t)((maxQ + 15) & ~15) + 4096; }
+size_t par_lds_bytes(int maxQ, int maxT, int waves = 0) {           // + KSCW's candidate arrays: 256 x (sum, index) per wave
+  return (size_t)((maxT + 15) & ~15) * 2 + (size_t)((maxQ + 15) & ~15) + 4096 + (size_t)waves * 256 * 8;
+}
 // waves per pair: context hint "enum_waves" (1 = the one-wave kernel, 2..16), else 16; 0 = not usable
 int par_waves(const aln_batch* b, int kind, int n_pairs) {
-  if (kind != ALN_ENUM_CW && kind != ALN_ENUM_UCW) return 0;
+  if (kind != ALN_ENUM_CW && kind != ALN_ENUM_UCW && kind != ALN_ENUM_KSCW) return 0;
   const int h = b->ctx->hints.enum_waves;
-  if (h == 1 || par_lds_bytes(b->maxQ, b->maxT) > 60000 || b->maxQ > 65535 || b->maxT > 65535) return 0;
+  if (h == 1 || par_lds_bytes(b->maxQ, b->maxT, 16) > 60000 || b->maxQ > 65535 || b->maxT > 65535) return 0;
   if (h >= 2) return std::min(h, 16);
   (void)n_pairs;
   return 16;                      // measured on 1024 config-4 pairs: 16 waves 0.33 s, 8 waves 0.48 s, 4 waves 0.75 s, one wave 4.6 s
@@ -502,22 +504,26 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   proto.tcn = b->d_tcn; proto.deltab = b->d_deltab; proto.deltab_off = b->d_deltab_off; proto.instab = b->d_instab;
   const bool sub = b->sim_kind == ALN_SIM_SUBMATRIX;
   const bool tpos = b->gapdev.model != ALN_GAP_AFFINE_CONST;
-  if (cr)
-    hipLaunchKernelGGL(enumerate_cr_kernel, dim3(1), dim3(64), cr_lds_bytes(a), ctx->stream, b->d_pairs, pair, proto,
-                       sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr,
-                       b->d_H, b->d_P, sub ? nullptr : b->d_S, a);
-  else if (ks)
-    hipLaunchKernelGGL(enumerate_ks_kernel, dim3(1), dim3(64), (size_t)a.cand_cap * 8, ctx->stream, b->d_pairs, pair, proto,
-                       sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr,
-                       b->d_H, b->d_P, sub ? nullptr : b->d_S, a);
-  else if (pw)
-    hipLaunchKernelGGL(enumerate_par_kernel, dim3(1), dim3(64 * pw), par_lds_bytes(b->maxQ, b->maxT), ctx->stream, b->d_pairs, pair, proto,
+  auto launch_one_wave = [&]() {
+    if (cr)
+      hipLaunchKernelGGL(enumerate_cr_kernel, dim3(1), dim3(64), cr_lds_bytes(a), ctx->stream, b->d_pairs, pair, proto,
+                         sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr,
+                         b->d_H, b->d_P, sub ? nullptr : b->d_S, a);
+    else if (ks)
+      hipLaunchKernelGGL(enumerate_ks_kernel, dim3(1), dim3(64), (size_t)a.cand_cap * 8, ctx->stream, b->d_pairs, pair, proto,
+                         sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr,
+                         b->d_H, b->d_P, sub ? nullptr : b->d_S, a);
+    else
+      hipLaunchKernelGGL(enumerate_kernel, dim3(1), dim3(64), 0, ctx->stream, b->d_pairs, pair, proto, sub ? b->d_qcodes : nullptr,
+                         sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr, b->d_H, b->d_P,
+                         sub ? nullptr : b->d_S, a);
+  };
+  if (pw)
+    hipLaunchKernelGGL(enumerate_par_kernel, dim3(1), dim3(64 * pw), par_lds_bytes(b->maxQ, b->maxT, pw), ctx->stream, b->d_pairs, pair, proto,
                        sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr,
                        b->d_H, b->d_P, sub ? nullptr : b->d_S, a);
   else
-  hipLaunchKernelGGL(enumerate_kernel, dim3(1), dim3(64), 0, ctx->stream, b->d_pairs, pair, proto, sub ? b->d_qcodes : nullptr,
-                     sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr, b->d_H, b->d_P,
-                     sub ? nullptr : b->d_S, a);
+    launch_one_wave();
   ETRY(hipGetLastError());
   int32_t hout[4] = {0, 0, 0, 0};
   ETRY(hipMemcpyAsync(hout, d_out, 12, hipMemcpyDeviceToHost, ctx->stream));
@@ -525,9 +531,7 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   bool used_par = pw != 0;
   if (used_par && hout[2] == kParSerial) {            // the set outgrows user_limit: the serial order decides what is cut
     used_par = false;
-    hipLaunchKernelGGL(enumerate_kernel, dim3(1), dim3(64), 0, ctx->stream, b->d_pairs, pair, proto, sub ? b->d_qcodes : nullptr,
-                       sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr, b->d_H, b->d_P,
-                       sub ? nullptr : b->d_S, a);
+    launch_one_wave();
     ETRY(hipGetLastError());
     ETRY(hipMemcpyAsync(hout, d_out, 12, hipMemcpyDeviceToHost, ctx->stream));
     ETRY(hipStreamSynchronize(ctx->stream));
@@ -551,7 +555,10 @@ extern "C" int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* no
   if (seed_opt) scores[0] = b->islocal ? res[pair].best : res[pair].corner;
   else for (int k = 0; k < n_ex; ++k) scores[k] = noa->existing_scores[k];
   std::vector<int32_t> uids;
-  if (ks) {
+  if (ks && used_par) {                               // uid = the alignment's place at creation (kscw.h:262), the seed's is 1 (:121)
+    uids.assign(n_as, -1);
+    for (int k = n_ex; k < n_as; ++k) uids[k] = k == n_ex ? 1 : k;
+  } else if (ks) {
     uids.assign(n_as, -1);
     ETRY(hipMemcpy(uids.data() + n_ex, a.uid + n_ex, (size_t)(n_as - n_ex) * 4, hipMemcpyDeviceToHost));
   }
@@ -823,12 +830,12 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
       hipLaunchKernelGGL(enumerate_cr_kernel, dim3(gn), dim3(64), cr_lds_bytes(a), ctx->stream, b->d_pairs, 0, proto,
                          sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr,
                          b->d_H, b->d_P, sub ? nullptr : b->d_S, a);
-    else if (ks)
-      hipLaunchKernelGGL(enumerate_ks_kernel, dim3(gn), dim3(64), (size_t)a.cand_cap * 8, ctx->stream, b->d_pairs, 0, proto,
+    else if (pw)
+      hipLaunchKernelGGL(enumerate_par_kernel, dim3(gn), dim3(64 * pw), par_lds_bytes(b->maxQ, b->maxT, pw), ctx->stream, b->d_pairs, 0, proto,
                          sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr,
                          b->d_H, b->d_P, sub ? nullptr : b->d_S, a);
-    else if (pw)
-      hipLaunchKernelGGL(enumerate_par_kernel, dim3(gn), dim3(64 * pw), par_lds_bytes(b->maxQ, b->maxT), ctx->stream, b->d_pairs, 0, proto,
+    else if (ks)
+      hipLaunchKernelGGL(enumerate_ks_kernel, dim3(gn), dim3(64), (size_t)a.cand_cap * 8, ctx->stream, b->d_pairs, 0, proto,
                          sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, tpos ? b->d_tgi : nullptr, tpos ? b->d_tge : nullptr,
                          b->d_H, b->d_P, sub ? nullptr : b->d_S, a);
     else

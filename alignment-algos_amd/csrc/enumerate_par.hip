@@ -25,8 +25,11 @@
 // the XCD's L2 back).  Sequence codes, the substitution table and the SuboptFlags row live in LDS; trie nodes, slots and tickets
 // are handed out with LDS atomics.  Results are bit-identical to enumerate_kernel's (tests run both against the reference's sets).
 #include "enum_common.h"
+#include "enum_sort.h"
 
 namespace aln {
+
+constexpr int kKsCap = 256;      // KSCW in this kernel: candidates of one branch node that may pass the threshold (more: the one-wave kernel)
 
 __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __restrict__ pairs, int pair, EvalDev proto,
                                                             const uint8_t* __restrict__ qcodes, const uint8_t* __restrict__ tcodes,
@@ -57,7 +60,8 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
   const PairDesc pd = pairs[pair];
   const int Q = pd.Q, T = pd.T, ld = pd.ld;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const bool cw = a.kind == ALN_ENUM_CW;
+  const bool cw = a.kind == ALN_ENUM_CW, ks = a.kind == ALN_ENUM_KSCW;
+  const bool constrained = cw || ks;                  // opt_path stops where the template's SuboptFlags bit flips
 
   // ---- per-pair constants into LDS: flags | template codes | query codes | 32 x 32 table -----------------------------------
   const int Tp = (T + 15) & ~15, Qp = (Q + 15) & ~15;
@@ -65,6 +69,8 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
   uint8_t* l_tc = l_fl + Tp;
   uint8_t* l_qc = l_tc + Tp;
   float* l_tab = reinterpret_cast<float*>(l_qc + Qp);
+  float* ks_sc = l_tab + 1024 + (size_t)w * kKsCap;                        // KSCW: this wave's candidate sums ...
+  int* ks_ix = reinterpret_cast<int*>(l_tab + 1024 + (size_t)(blockDim.x >> 6) * kKsCap) + (size_t)w * kKsCap;   // ... and indices
   for (int i = threadIdx.x; i < T; i += blockDim.x) l_fl[i] = a.flags[i];
   const bool sub = proto.sim_kind == ALN_SIM_SUBMATRIX;
   if (sub) {
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
     s_alloc = (unsigned long long)kChunkNodes;        // "current chunk is full": the first allocation fetches one
     uint32_t* tk = a.task;                                                            // branch(final cell, seed slot)  cw.h:92 / ucw.h:86
     st_w(tk + 0, ((uint32_t)(Q - 1) << 16) | (uint32_t)(T - 1)); st_w(tk + 1, (uint32_t)a.first_slot); st_w(tk + 2, kNoNode);
-    st_w(tk + 3, __float_as_uint(0.f)); st_w(tk + 4, 1u);
+    st_w(tk + 3, __float_as_uint(0.f)); st_w(tk + 4, 1u); st_w(tk + 6, a.k_limit);
     __hip_atomic_store(tk + 5, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // ticket 0 is ready
     st_u(&a.head[a.first_slot], kNoNode); st_f(&a.score[a.first_slot], 0.f);
   }
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
     }
     tkt = __shfl(tkt, 0);
     if (tkt < 0) break;
-    uint32_t tw0, tw1, tw2, tw3, tw4;
+    uint32_t tw0, tw1, tw2, tw3, tw4, tw6;
     {
       const uint32_t* tk = a.task + (size_t)((uint32_t)tkt % qcap) * kTaskWords;
       bool ready = false;
@@ -184,9 +190,9 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
         if (lane == 0) atomicCAS(&s_status, 0, ALN_E_OVERFLOW);
         break;
       }
-      const uint32_t v = lane < 5 ? ld_w(tk + lane) : 0u;
+      const uint32_t v = lane < 7 ? ld_w(tk + lane) : 0u;
       tw0 = (uint32_t)__shfl((int)v, 0); tw1 = (uint32_t)__shfl((int)v, 1); tw2 = (uint32_t)__shfl((int)v, 2);
-      tw3 = (uint32_t)__shfl((int)v, 3); tw4 = (uint32_t)__shfl((int)v, 4);
+      tw3 = (uint32_t)__shfl((int)v, 3); tw4 = (uint32_t)__shfl((int)v, 4); tw6 = (uint32_t)__shfl((int)v, 6);
     }
 
     // ---- one task: opt_path / branch of ONE alignment slot until its branch node has spawned its children ---------------
@@ -195,6 +201,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
     uint32_t hd = tw2;
     float sc = __uint_as_float(tw3);
     bool is_branch = (tw4 & 1u) != 0, force = (tw4 & 2u) != 0;
+    uint32_t klimit = tw6;                                // KSCW: operations this alignment's next branch node may keep (kscw.h:246-247)
     bool dead = false;
     if (q0 < 1 || t0 < 1 || q0 >= Q || t0 >= T || slot >= a.ali_cap) { fail(ALN_E_OVERFLOW); break; }   // not a record of this search
 
@@ -215,12 +222,13 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
       if (++guard > 2 * (Q + T) + 64) { fail(ALN_E_OVERFLOW); break; }       // (a path that never reaches row / column 1: not a DP matrix)
       if (q0 == 1 || t0 == 1) { base_case(); break; }                      // cw.h:220-228, :113-121
       if (!is_branch) {
+        if (ks && klimit <= 1) force = true;                              // kscw.h:297-299
         // opt_path: follow stored pointers, 64 diagonal cells at a time (see enumerate.hip walk())
-        const bool flag = cw ? !l_fl[t0] : false;
+        const bool flag = constrained ? !l_fl[t0] : false;
         while (t0 > 1 && q0 > 1) {
           const int q = q0 - lane, t = t0 - lane;
           bool stop = !(q > 1 && t > 1);
-          if (!stop && cw && !force && ((l_fl[t] != 0) == flag)) stop = true;
+          if (!stop && constrained && !force && ((l_fl[t] != 0) == flag)) stop = true;
           int pq = 0, pt = 0; float sv = 0.f, g = 0.f;
           if (!stop) {
             const uint32_t p = load_ptr_word(Pbase, pd.plane_off, ld, q, t, a.ptr_mode);
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
           } else { q0 -= n_proc; t0 -= n_proc; }
         }
         if (dead) break;
-        if (!cw) { base_case(); break; }                                    // ucw.h:232-234
+        if (!constrained) { base_case(); break; }                           // ucw.h:232-234
         is_branch = true;                                                   // branch(pq,pt,k0,force)  cw.h:276
         continue;
       }
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
       bool first = true;                                                    // the first accepted candidate continues in `slot`
       // every accepted candidate of one 64-candidate group: a trie node (q0,t0) in front of hd, a slot (new ones are recorded
       // with their place in the reference's order) and a task
-      auto spawn = [&](unsigned long long m, float g, int cq, int ct, int idx) {
+      auto spawn = [&](unsigned long long m, float g, int cq, int ct, int idx, uint32_t lim = 0u) {
         const int n = __popcll(m);
         const int nnew = n - (first ? 1 : 0);
         uint32_t bt = 0, bn = 0, bs = 0;
@@ -298,11 +306,60 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
           const uint32_t ticket = bt + (uint32_t)rnk;
           uint32_t* tk = a.task + (size_t)(ticket % qcap) * kTaskWords;
           st_w(tk + 0, ((uint32_t)cq << 16) | (uint32_t)ct); st_w(tk + 1, sl); st_w(tk + 2, nd);
-          st_w(tk + 3, __float_as_uint(r - g)); st_w(tk + 4, cw ? 0u : 1u);   // cw: opt_path(cand, k, false); ucw: branch(cand, k)
+          st_w(tk + 3, __float_as_uint(r - g)); st_w(tk + 4, constrained ? 0u : 1u);   // cw, kscw: opt_path(cand, k, false); ucw: branch(cand, k)
+          st_w(tk + 6, lim);
           __hip_atomic_store(tk + 5, ticket + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         first = false;
       };
+      if (ks) {
+        // KSConstrainedNearOptimal's branch node (kscw.h:139-288): EVERY passing predecessor in the reference's scan order into this
+        // wave's LDS arrays, libstdc++'s sort / partial_sort on them (enum_sort.h, one lane: the order of equal scores is observable),
+        // the k_limit best become the node's operations — the best keeps (about) the node's limit, the others get half of it.
+        int n = 0;
+        for (int base = 0; base < ncand; base += 64) {
+          const int idx = base + lane;
+          bool ok = false; float sum = 0.f;
+          if (idx < ncand) {
+            if (idx == 0) sum = HV(q0 - 1, t0 - 1) + r;
+            else if (idx <= ndel) { const int pt = t0 - 1 - idx; sum = HV(q0 - 1, pt) + r - dev_deletion(e, pt, t0); }
+            else { const int pq = q0 - 2 - (idx - ndel - 1); sum = HV(pq, t0 - 1) + r - dev_insertion(e, pq, q0, t0 - 1, t0); }
+            ok = sum > thr;
+          }
+          const unsigned long long m = __ballot(ok);
+          if (m) {
+            const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+            if (ok && pos < kKsCap) { ks_sc[pos] = sum; ks_ix[pos] = idx; }
+            n += __popcll(m);
+          }
+        }
+        if (n > kKsCap) { fail(kParSerial); break; }                        // more candidates than this kernel keeps per wave
+        if (n == 0) { is_branch = false; force = true; klimit = 1; continue; }   // kscw.h:222-228: op(1, q0, t0, k0), forced
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        int m_keep = n;
+        if (lane == 0) {
+          kssort::Arr arr = {ks_sc, ks_ix};
+          if ((uint32_t)n > klimit) kssort::partial_sort(arr, 0, (int)klimit, n);
+          else kssort::sort(arr, 0, n);
+        }
+        if ((uint32_t)n > klimit) m_keep = (int)klimit;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (m_keep == 0) { fail(ALN_E_ARG); break; }                        // limit 0 with candidates (`it->limit *= 2` on an empty vector in the reference)
+        int pq = q0 - 1, pt = t0 - 1; float g = 0.f;
+        if (lane < m_keep) {
+          const int idx = ks_ix[lane];
+          if (idx == 0) { }
+          else if (idx <= ndel) { pt = t0 - 1 - idx; g = dev_deletion(e, pt, t0); }
+          else { pq = q0 - 2 - (idx - ndel - 1); pt = t0 - 1; g = dev_insertion(e, pq, q0, pt, t0); }
+        }
+        uint32_t lim = klimit / 2;
+        if (lane == 0) lim *= 2;                                            // only the best operation keeps (about) the node's limit
+        spawn(m_keep >= 64 ? ~0ull : ((1ull << m_keep) - 1ull), g, pq, pt, lane, lim);   // ordinal = place in the sorted list
+        __builtin_amdgcn_wave_barrier();
+        break;                                                              // the operations carry on
+      }
       const bool fdel = (e.align_type == ALN_LOCAL || e.align_type == ALN_SEMI_LOCAL || e.align_type == ALN_LOCAL_GLOBAL);
       const bool fins = (e.align_type == ALN_LOCAL || e.align_type == ALN_SEMI_LOCAL || e.align_type == ALN_GLOBAL_LOCAL);
       const uint16_t* H16p = reinterpret_cast<const uint16_t*>(Hbase) + pd.plane_off;

@@ -189,7 +189,8 @@ int aln_has_gfx950(void);
  *                                   barriers; wants >= 2048 pairs in flight, i.e. two 1024-pair launches on two streams)
  *   "dp_variant_nw" "dp_variant_r" "dp_variant_x"   force a row-sweep instantiation (0 = automatic)
  *   "exact_tiles" "exact_literal" "exact_alt_prio" "score_packed" "enum_node_cap" "tag_lag"
- *   "enum_waves"                    ConstrainedNearOptimal / UnconstrainedNearOptimal search: waves per pair (2..16, enumerate_par.hip);
+ *   "enum_waves"                    ConstrainedNearOptimal / UnconstrainedNearOptimal / KSConstrainedNearOptimal search: waves per pair
+ *                                   (2..16, enumerate_par.hip);
  *                                   1 = the one-wave kernel; 0 (default) = 16.  Same sets, same order.
  *   "enum_debug"                    1: aln_batch_enumerate_all reports every group of pairs it searches (pools, times, retries) on stderr
  *   "enum_keep_pools"               1 (default): aln_batch_enumerate_all keeps its device pools with the batch until the batch is destroyed
@@ -274,8 +275,8 @@ int aln_batch_enumerate(aln_batch* b, int32_t pair, const aln_noa* noa, const ui
                         int32_t* pairs, int64_t pairs_capacity, int32_t* n_out);
 
 /* The same enumeration for EVERY pair of the resident batch in one launch (BASELINE config 4: top-K near-optimal
- * tracebacks per pair from the GPU-resident matrices): one workgroup per pair runs its search (cw / ucw: 16 waves share it,
- * csrc/enumerate_par.hip; the pruned enumerators: one wave), the host runs sortSet(number_suboptimal) per pair on (score,
+ * tracebacks per pair from the GPU-resident matrices): one workgroup per pair runs its search (cw / ucw / kscw: 16 waves share
+ * it, csrc/enumerate_par.hip; crcw: one wave), the host runs sortSet(number_suboptimal) per pair on (score,
  * index) keys in the reference's set order, survivors are unrolled on the device.  Every set is seeded with the pair's Optimal
  * alignment (noa->n_existing is ignored).
  *   flags: SuboptFlags rows, pair p's row at flags + p * flags_stride (flags_stride 0: one shared row of max T bytes);

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(params=[1, 0, 3], ids=["one_wave", "waves_auto", "waves3"])
 def enum_waves(request):
-    """cw / ucw searches run in the one-wave kernel (enumerate.hip) and in the several-waves-per-pair kernel (enumerate_par.hip:
+    """cw / ucw / kscw searches run in the one-wave kernels (enumerate.hip, enumerate_ks.hip) and in the several-waves-per-pair kernel (enumerate_par.hip:
     tasks, slot tree, set order rebuilt on the host) — same sets, same order."""
     with gpu_util.ctx().hints(enum_waves=request.param):
         yield request.param
@@ -166,7 +166,7 @@ def test_batched_enumeration_overflow_is_per_pair(blosum62, enum_waves):
     b.close()
 
 
-def test_kscw_vs_oracle(blosum62):
+def test_kscw_vs_oracle(blosum62, enum_waves):
     """KSConstrainedNearOptimal (kscw.h:109-351) on the device: per-node candidate collection, libstdc++-ordered sort /
     partial_sort of the operations, halving limits, forced optimal paths — against the oracle's restatement (which sorts with
     the host's std::sort / std::partial_sort).  Parity UNPINNED against the reference (its header does not build on LP64)."""
@@ -204,7 +204,7 @@ def test_kscw_vs_oracle(blosum62):
         b.close()
 
 
-def test_batched_kscw_matches_single_pair_and_oracle(blosum62):
+def test_batched_kscw_matches_single_pair_and_oracle(blosum62, enum_waves):
     """aln_batch_enumerate_all with ALN_ENUM_KSCW: every pair of a ragged batch in one launch (one workgroup per pair, own
     pool slices); set size, order, score bits and pair lists against the one-pair entry point and the oracle's restatement."""
     alpha, table = blosum62
