@@ -355,7 +355,7 @@ size_t par_lds_bytes(int maxQ, int maxT, int waves = 0) {           // + KSCW's 
 int par_waves(const aln_batch* b, int kind, int n_pairs) {
   if (kind != ALN_ENUM_CW && kind != ALN_ENUM_UCW && kind != ALN_ENUM_KSCW) return 0;
   const int h = b->ctx->hints.enum_waves;
-  if (h == 1 || par_lds_bytes(b->maxQ, b->maxT, 16) > 60000 || b->maxQ > 65535 || b->maxT > 65535) return 0;
+  if (h == 1 || par_lds_bytes(b->maxQ, b->maxT, 16) > 58000 || b->maxQ > 65535 || b->maxT > 65535) return 0;
   if (h >= 2) return std::min(h, 16);
   (void)n_pairs;
   return 16;                      // measured on 1024 config-4 pairs: 16 waves 0.33 s, 8 waves 0.48 s, 4 waves 0.75 s, one wave 4.6 s
