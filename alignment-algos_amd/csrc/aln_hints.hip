@@ -27,6 +27,7 @@ const HintDef kDefs[] = {
     {"tag_segments", "ALN_TAG_SEGMENTS", false, &aln_hints::tag_segments},
     {"tag_solo", "ALN_TAG_SOLO", false, &aln_hints::tag_solo},
     {"tag_bits", "ALN_TAG_BITS", false, &aln_hints::tag_bits},
+    {"tag_occupancy", "ALN_TAG_OCCUPANCY", false, &aln_hints::tag_occupancy},
     {"dp_variant_nw", nullptr, false, &aln_hints::dp_nw},
     {"dp_variant_r", nullptr, false, &aln_hints::dp_r},
     {"dp_variant_x", nullptr, false, &aln_hints::dp_x},

@@ -65,6 +65,7 @@ struct aln_hints {
                              // synchronous per-row exchange.  Measured on MI355X (config 2, lone launches): lag 0 3.11 ms, 1: 3.20, 2: 3.10,
                              // 4: 3.28; four overlapping streams 2.82 vs 3.38 — the waves of a pair drifting apart costs more in HBM
                              // row locality (the two halves of a plane row are written rows apart) than the barrier chain it removes
+  int tag_occupancy = 0;     // tagged kernel, 16-cell lanes: waves per SIMD it is compiled for: 2, 3, or 0 = three when the launch alone has >= 3 per SIMD
   int tag_bits = 0;          // 12: the 12-tag-bit layout (pointer dialect 2) also for sequences of up to 2048 residues (tests); 0 = by length
   int tag_solo = 0;          // 1: pairs of 1025..2048 columns run in dp_affine_solo (one wave per pair, no barriers; wants >= 2048 pairs in flight)
   int tag_segments = 0;      // tagged kernel: (pair, row segment) work items handed out by a queue (dp_affine_tag.hip "Segment queue"):

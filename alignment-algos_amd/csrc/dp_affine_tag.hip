@@ -42,8 +42,8 @@ __device__ __forceinline__ void setprio_dyn(int p) {     // s_setprio takes an i
 }
 
 // SEGQ: workgroups take (pair, row segment) items from the queue instead of building pair blockIdx.x from first to last row.
-template <int NW, int R, bool LOCAL, bool H16, int KBT, int X, bool SEGQ, int TB>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X == 16 ? 2 : 1, R * X == 16 ? 2 : 8))) void dp_affine_tag_kernel(
+template <int NW, int R, bool LOCAL, bool H16, int KBT, int X, bool SEGQ, int TB, int OCC>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X == 16 ? OCC : 1, R * X == 16 ? OCC : 8))) void dp_affine_tag_kernel(
     const PairDesc* __restrict__ pairs, const uint8_t* __restrict__ qcodes, const uint8_t* __restrict__ tcodes,
     const int32_t* __restrict__ table32, float* __restrict__ Hbase, uint32_t* __restrict__ Pbase,
     PairResult* __restrict__ res, TagParams prm) {
@@ -587,9 +587,19 @@ static int launch_tag_variant(aln_batch* b, const TagParams& prm_in) {
   }
   b->tag_segmented = segq;
   const bool k16 = b->islocal && b->h_mode == 1 && tag_key16_legal(b) && b->ctx->hints.key16;
-#define ALN_TAG_LAUNCH(LOC_, H16_, KB_, SQ_)                                                                                         \
-  hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, LOC_, H16_, KB_, X, SQ_, TB>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, \
+  // 16 cells per lane (155 VGPRs): two or three waves per SIMD.  Three pay when enough waves are in flight to give EVERY SIMD three
+  // (launches of several contexts overlapping, or >= 1536 pairs in one launch: -8 % per step in bench.py); a lone 1024-pair launch
+  // (2048 waves on 1024 SIMDs) is spread unevenly by the dispatcher then, 3 on some SIMDs and 1 on others (+20 %).  Context hint
+  // "tag_occupancy": 2, 3, or 0 = by the size of this launch.
+  const int occ_hint = b->ctx->hints.tag_occupancy;
+  const bool occ3 = R * X == 16 && !segq && (occ_hint == 3 || (occ_hint == 0 && (long)b->n_pairs * NW >= 3072));
+#define ALN_TAG_LAUNCH_O(LOC_, H16_, KB_, SQ_, OCC_)                                                                                 \
+  hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, LOC_, H16_, KB_, X, SQ_, TB, OCC_>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, \
                      b->d_table32, b->d_H, b->d_P, b->d_res, prm)
+#define ALN_TAG_LAUNCH(LOC_, H16_, KB_, SQ_) do {                                                                                    \
+    if constexpr (R * X == 16 && !(SQ_)) { if (occ3) ALN_TAG_LAUNCH_O(LOC_, H16_, KB_, SQ_, 3); else ALN_TAG_LAUNCH_O(LOC_, H16_, KB_, SQ_, 2); } \
+    else ALN_TAG_LAUNCH_O(LOC_, H16_, KB_, SQ_, 2);                                                                                  \
+  } while (0)
 #define ALN_TAG_LAUNCH_Q(LOC_, H16_, KB_) do { if (segq) ALN_TAG_LAUNCH(LOC_, H16_, KB_, true); else ALN_TAG_LAUNCH(LOC_, H16_, KB_, false); } while (0)
   if (k16) ALN_TAG_LAUNCH_Q(true, true, 16);
   else if (b->islocal && b->h_mode == 1) ALN_TAG_LAUNCH_Q(true, true, 13);
@@ -597,9 +607,10 @@ static int launch_tag_variant(aln_batch* b, const TagParams& prm_in) {
   else ALN_TAG_LAUNCH_Q(false, false, 13);
 #undef ALN_TAG_LAUNCH_Q
 #undef ALN_TAG_LAUNCH
+#undef ALN_TAG_LAUNCH_O
   char nm[96];
-  snprintf(nm, sizeof nm, "dp_affine_tag_kernel<NW=%d,R=%d,%s%s%s%s%s>%s", NW, R, X == 8 ? "X=8," : "", b->islocal ? "local" : "global",
-           b->h_mode == 1 ? ",h16" : "", k16 ? ",key16" : "", TB == 12 ? ",tag12" : "", segq ? "+segq" : "");
+  snprintf(nm, sizeof nm, "dp_affine_tag_kernel<NW=%d,R=%d,%s%s%s%s%s%s>%s", NW, R, X == 8 ? "X=8," : "", b->islocal ? "local" : "global",
+           b->h_mode == 1 ? ",h16" : "", k16 ? ",key16" : "", TB == 12 ? ",tag12" : "", occ3 ? ",occ3" : "", segq ? "+segq" : "");
   b->kernel_name = nm;
   ALN_HIP_CHECK(b->ctx, hipGetLastError());
   return ALN_OK;

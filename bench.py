@@ -209,6 +209,7 @@ def main():
     ap.add_argument("--streams", "--batches", dest="batches", type=int, default=4,
                     help="HIP streams (contexts) the launches rotate over (1 = everything on one stream)")
     ap.add_argument("--alt-prio", type=int, default=-1, help="tagged kernel's row-alternating wave priority: -1 = on for one stream, off for several")
+    ap.add_argument("--occupancy", type=int, default=-1, help="tagged kernel's waves per SIMD (2 or 3): -1 = 3 for several streams, 2 for one")
     ap.add_argument("--split", type=int, default=2,
                     help="launches a step's batch is processed in (sub-batches of pairs/split pairs; 1 = one launch per step)")
     args = ap.parse_args()
@@ -251,6 +252,7 @@ def main():
     ctxs = [aln_amd.Context(local_rank, st.cuda_stream) for st in streams]
     for c in ctxs:
         c.set_hint("tag_alt_prio", (1 if nb == 1 else 0) if args.alt_prio < 0 else args.alt_prio)    # pays on lone launches only
+        c.set_hint("tag_occupancy", (3 if nb > 1 else 2) if args.occupancy < 0 else args.occupancy)  # 3 waves/SIMD pay once launches overlap
     units = {}                                              # (stream, sub-batch) -> resident batch object
     j = 0
     while (j % nb, j % split) not in units:
@@ -442,6 +444,7 @@ def main():
         # strings + identities built — one lone launch sequence per step on one stream, nothing pipelined
         c0 = ctxs[0]
         c0.set_hint("tag_alt_prio", 1)
+        c0.set_hint("tag_occupancy", 2)
         be = aln_amd.Batch(c0, qs, ts)
         be.dp_submatrix(alphabet, table, mode, gi, ge, aln_amd.FWD, aln_amd.DP_FAST)
         be.optimal_strings(decode=False)

@@ -176,13 +176,16 @@ int aln_ctx_synchronize(aln_ctx* ctx);
 int aln_has_gfx950(void);
 /* Tuning / kernel-selection hints of ONE context.  A context reads its defaults from the environment once, when it is created
  * (ALN_NO_TAG_KERNEL, ALN_NO_H16, ALN_NO_KEY16, ALN_TAG_ALT_PRIO, ALN_TAG_SEGMENTS, ALN_DP_VARIANT="NW,R[,X]", ALN_EXACT_NO_TILES,
- * ALN_EXACT_LITERAL, ALN_EXACT_ALT_PRIO, ALN_SCORE_NO_PACKED, ALN_ENUM_NODE_CAP, ALN_TAG_LAG, ALN_TAG_SOLO, ALN_TAG_BITS, ALN_PLANE_ROW_ALIGN, ALN_ENUM_POOL_RETRIES, ALN_ENUM_WAVES, ALN_ENUM_DEBUG, ALN_ENUM_KEEP_POOLS); launches never read the environment.  Keys:
+ * ALN_EXACT_LITERAL, ALN_EXACT_ALT_PRIO, ALN_SCORE_NO_PACKED, ALN_ENUM_NODE_CAP, ALN_TAG_LAG, ALN_TAG_SOLO, ALN_TAG_BITS, ALN_TAG_OCCUPANCY, ALN_PLANE_ROW_ALIGN, ALN_ENUM_POOL_RETRIES, ALN_ENUM_WAVES, ALN_ENUM_DEBUG, ALN_ENUM_KEEP_POOLS); launches never read the environment.  Keys:
  *   "tag_kernel" "h16" "key16"     1/0: tagged-key kernel / uint16 score plane / 16-bit key layout allowed (results identical)
  *   "tag_alt_prio"                  1/0: row-alternating wave priority in the tagged kernel (a scheduling hint; pays when launches
  *                                   follow each other on one stream, loses when launches of several contexts overlap);
  *                                   2, 3 and 0x100 | four 2-bit levels: experimental schedules (dp_affine_tag.hip, row loop)
  *   "tag_segments"                  tagged kernel: 0 (default) one workgroup per pair; K in 2..8: long pairs are cut into K row
  *                                   segments handed out by a device queue when the batch alone fills the GPU; -K: whenever pairs are long
+ *   "tag_occupancy"                 tagged kernel: 2 or 3 waves per SIMD (two builds of the 16-cells-per-lane instantiations); 0 (default):
+ *                                   3 when the launch alone brings >= 3 waves per SIMD (>= 1536 pairs of two waves), else 2.  A caller
+ *                                   that overlaps launches of several contexts sets 3 (bench.py: -8 % per step).
  *   "tag_bits"                      12: the 12-tag-bit key layout (pointer dialect 2, sequences up to 4096) also for shorter sequences;
  *                                   0 (default): by length.  Results do not depend on it.
  *   "tag_solo"                      1: templates of up to 2048 columns run in the one-wave-per-pair kernel (dp_affine_solo.hip: no

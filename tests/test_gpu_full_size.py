@@ -65,10 +65,11 @@ def check_opt(gold, score, pairs, what):
     assert np.asarray(pairs, np.int32).reshape(-1).tolist() == gold["opt"]["pairs"], what
 
 
-@pytest.mark.parametrize("kernel", ["tag", "solo", "tag_segq", "tag_nw1", "int"])
+@pytest.mark.parametrize("kernel", ["tag", "tag_occ3", "solo", "tag_segq", "tag_nw1", "int"])
 def test_c2_planes_and_optimal_equal_the_reference(kernel, blosum62):
-    """Config 2: the 8 pinned pairs of the bench workload, local 11/1.  `tag` is the instantiation bench.py times
-    (NW=2,R=2,X=8,local,h16,key16), one workgroup per pair; `tag_segq` the same instantiation with the segment queue bench.py's
+    """Config 2: the 8 pinned pairs of the bench workload, local 11/1.  `tag` is the instantiation of a lone launch
+    (NW=2,R=2,X=8,local,h16,key16, two waves per SIMD), `tag_occ3` its three-waves-per-SIMD build, which bench.py's overlapping
+    launches use; one workgroup per pair; `tag_segq` the same instantiation with the segment queue bench.py's
     1024-pair launches use (every pair built by six workgroups that hand the row state on through HBM); `tag_nw1` a
     one-wave-per-pair instantiation; `solo` the one-wave-per-pair kernel that visits a pair's four 512-column strips in turn
     (dp_affine_solo.hip); `int` the untagged O(n^2) kernel."""
@@ -78,15 +79,15 @@ def test_c2_planes_and_optimal_equal_the_reference(kernel, blosum62):
     for g, q, t in zip(gold, qs, ts):
         assert hashlib.sha256(q.encode()).hexdigest() == g["q_sha"] and hashlib.sha256(t.encode()).hexdigest() == g["t_sha"]
     ctx = gpu_util.ctx()
-    hints = {"tag": {"tag_segments": 0}, "tag_segq": {"tag_segments": -6}, "solo": {"tag_solo": 1},
+    hints = {"tag": {"tag_segments": 0, "tag_occupancy": 2}, "tag_occ3": {"tag_segments": 0, "tag_occupancy": 3}, "tag_segq": {"tag_segments": -6}, "solo": {"tag_solo": 1},
              "tag_nw1": {"dp_variant_nw": 1, "dp_variant_r": 4, "dp_variant_x": 8, "tag_segments": -6}, "int": {"tag_kernel": 0}}[kernel]
     with ctx.hints(**hints):
         b = aln_amd.Batch(ctx, list(qs), list(ts))
         b.dp_submatrix(alpha, table, aln_amd.LOCAL, 11, 1, aln_amd.FWD, aln_amd.DP_FAST)
     kn = b.kernel_name()
-    if kernel in ("tag", "tag_segq"):
+    if kernel in ("tag", "tag_occ3", "tag_segq"):
         assert kn.startswith("dp_affine_tag") and "NW=2,R=2,X=8,local,h16,key16" in kn, kn
-        assert kn.endswith("+segq") == (kernel == "tag_segq"), kn
+        assert kn.endswith("+segq") == (kernel == "tag_segq") and ("occ3" in kn) == (kernel == "tag_occ3"), kn
         assert b.plane_bytes_per_cell() == 4
     elif kernel == "solo":
         assert kn == "dp_affine_solo_kernel<local,h16,key16,occ3>", kn
