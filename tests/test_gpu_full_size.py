@@ -253,7 +253,7 @@ def long_pair(g):
     return random_pair(g["seed"], g["qlen"], g["tlen"])
 
 
-@pytest.mark.parametrize("kernel", ["tag", "int", "exact"])
+@pytest.mark.parametrize("kernel", ["tag", "tag_occ3", "int", "exact"])
 def test_pairs_beyond_2048_residues_equal_the_reference(kernel, blosum62):
     """The reference has no length limit (dpmatrix.h:250-259).  Pairs between 2049 and 4094 residues, local 11/1: the tagged
     kernel's 12-tag-bit layout (one instantiation, 4 waves x 1024 columns, pointer dialect 2), the untagged O(n^2) kernel
@@ -264,13 +264,13 @@ def test_pairs_beyond_2048_residues_equal_the_reference(kernel, blosum62):
     for g, (q, t) in zip(gold, prs):
         assert hashlib.sha256(q.encode()).hexdigest() == g["q_sha"] and hashlib.sha256(t.encode()).hexdigest() == g["t_sha"]
     ctx = gpu_util.ctx()
-    hints = {"tag": {}, "int": {"tag_kernel": 0}, "exact": {}}[kernel]
+    hints = {"tag": {"tag_occupancy": 2}, "tag_occ3": {"tag_occupancy": 3}, "int": {"tag_kernel": 0}, "exact": {}}[kernel]
     with ctx.hints(**hints):
         b = aln_amd.Batch(ctx, [p[0] for p in prs], [p[1] for p in prs])
         b.dp_submatrix(alpha, table, aln_amd.LOCAL, 11, 1, aln_amd.FWD, aln_amd.DP_EXACT if kernel == "exact" else aln_amd.DP_FAST)
     kn = b.kernel_name()
-    if kernel == "tag":
-        assert kn.startswith("dp_affine_tag") and "NW=4,R=2,X=8" in kn and "tag12" in kn, kn
+    if kernel in ("tag", "tag_occ3"):
+        assert kn.startswith("dp_affine_tag") and "NW=4,R=2,X=8" in kn and "tag12" in kn and ("occ3" in kn) == (kernel == "tag_occ3"), kn
         assert b.plane_bytes_per_cell() == 4
     elif kernel == "int":
         assert kn.startswith("dp_affine_int"), kn
