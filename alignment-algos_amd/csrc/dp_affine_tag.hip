@@ -588,11 +588,15 @@ static int launch_tag_variant(aln_batch* b, const TagParams& prm_in) {
   b->tag_segmented = segq;
   const bool k16 = b->islocal && b->h_mode == 1 && tag_key16_legal(b) && b->ctx->hints.key16;
   // 16 cells per lane (155 VGPRs): two or three waves per SIMD.  Three pay when enough waves are in flight to give EVERY SIMD three
-  // (launches of several contexts overlapping, or >= 1536 pairs in one launch: -8 % per step in bench.py); a lone 1024-pair launch
+  // (launches of several contexts overlapping: -8 % per step in bench.py; or a lone launch of 1536 pairs); a lone 1024-pair launch
   // (2048 waves on 1024 SIMDs) is spread unevenly by the dispatcher then, 3 on some SIMDs and 1 on others (+20 %).  Context hint
   // "tag_occupancy": 2, 3, or 0 = by the size of this launch.
   const int occ_hint = b->ctx->hints.tag_occupancy;
-  const bool occ3 = R * X == 16 && !segq && (occ_hint == 3 || (occ_hint == 0 && (long)b->n_pairs * NW >= 3072));
+  // by the size of the launch: waves per SIMD it brings (1024 SIMDs), rounds of 2 (3.2 ms each, measured on config 2) against rounds
+  // of 3 (4.5 ms): 1024 pairs -> 2, 1536 -> 3 (4.6 vs 6.3 ms), 2048 -> 2 (6.9 vs 7.5 ms)
+  const long wps = ((long)b->n_pairs * NW + 1023) / 1024;
+  const bool auto3 = ((wps + 2) / 3) * 45 < ((wps + 1) / 2) * 32;
+  const bool occ3 = R * X == 16 && !segq && (occ_hint == 3 || (occ_hint == 0 && auto3));
 #define ALN_TAG_LAUNCH_O(LOC_, H16_, KB_, SQ_, OCC_)                                                                                 \
   hipLaunchKernelGGL((dp_affine_tag_kernel<NW, R, LOC_, H16_, KB_, X, SQ_, TB, OCC_>), grid, block, 0, st, b->d_pairs, b->d_qcodes, b->d_tcodes, \
                      b->d_table32, b->d_H, b->d_P, b->d_res, prm)

@@ -184,7 +184,7 @@ int aln_has_gfx950(void);
  *   "tag_segments"                  tagged kernel: 0 (default) one workgroup per pair; K in 2..8: long pairs are cut into K row
  *                                   segments handed out by a device queue when the batch alone fills the GPU; -K: whenever pairs are long
  *   "tag_occupancy"                 tagged kernel: 2 or 3 waves per SIMD (two builds of the 16-cells-per-lane instantiations); 0 (default):
- *                                   3 when the launch alone brings >= 3 waves per SIMD (>= 1536 pairs of two waves), else 2.  A caller
+ *                                   by the waves per SIMD the launch alone brings (rounds of 3 against rounds of 2).  A caller
  *                                   that overlaps launches of several contexts sets 3 (bench.py: -8 % per step).
  *   "tag_bits"                      12: the 12-tag-bit key layout (pointer dialect 2, sequences up to 4096) also for shorter sequences;
  *                                   0 (default): by length.  Results do not depend on it.
