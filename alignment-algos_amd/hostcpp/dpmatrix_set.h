@@ -8,9 +8,11 @@
 //     set.scores() (Optimal's score of every pair)
 // — from ONE resident batch: one aln_batch_dp, one aln_batch_optimal for all pairs.  Evaluator families:
 //   * AASubstitutionEval (codes + table + constant affine gaps): lowered once, nothing per pair on the host;
+//   * Hmap2Eval / HMAPaliEval (profiles + position-minimum gaps): the pairs' profile records and gap coefficients are pooled in
+//     pair order, similarity + z-normalisation run on the device for all pairs — what a loop of nalign2-style builds becomes;
 //   * any other evaluator: similarity()/post_process() evaluated per pair on the host into planes (as DPMatrix does) and the
-//     gap model it names itself (aln_describe_gaps, constant affine).  Evaluators that need per-position or tabulated gap
-//     functions are built pair by pair with DPMatrix (their lowering is per pair by nature).
+//     gap model it names itself (aln_describe_gaps, constant affine).  Evaluators whose gap functions must be tabulated
+//     (Gn2Eval's tables, plain plugins) are built pair by pair with DPMatrix (their lowering is per pair by nature).
 // Ownership as in DPMatrix: sequences and evaluator are borrowed, the matrices are the set's.
 #ifndef ALN_HOST_DPMATRIX_SET_H
 #define ALN_HOST_DPMATRIX_SET_H
@@ -118,6 +120,27 @@ class DPMatrixSet {
     if (n == 0) return;
     for (size_t p = 0; p < n; ++p) evaluator->pre_calculate(*qs[p], *ts[p]);                 // dpmatrix.h:298
     aln::Lowering<S1, S2, Etype>::lower(*qs[0], *ts[0], evaluator->Derived(), L);
+    std::vector<float> q_aa, q_sse, q_conf, t_aa, t_sse, t_conf, t_gi, t_ge;    // profile pools (Hmap2Eval / HMAPaliEval)
+    if (L.sim.kind == ALN_SIM_HMAP2 && L.gap.model == ALN_GAP_AFFINE_TPOS_MIN) {
+      // profile evaluators: per-position records and per-template-position gap coefficients, pooled in pair order like the residues
+      auto app = [](std::vector<float>& dst, const std::vector<float>& src) { dst.insert(dst.end(), src.begin(), src.end()); };
+      for (size_t p = 0; p < n; ++p) {
+        aln::Lowered Lp;
+        if (p) aln::Lowering<S1, S2, Etype>::lower(*qs[p], *ts[p], evaluator->Derived(), Lp);
+        const aln::Lowered& X = p ? Lp : L;
+        if (X.sim.kind != ALN_SIM_HMAP2 || X.sim.alpha != L.sim.alpha || X.sim.zero_shift != L.sim.zero_shift || X.gap.align_type != L.gap.align_type)
+          throw std::string("DPMatrixSet: the evaluator's parameters differ from pair to pair; build DPMatrix objects");
+        app(q_aa, X.q_aa); app(q_sse, X.q_sse); app(q_conf, X.q_conf);
+        app(t_aa, X.t_aa); app(t_sse, X.t_sse); app(t_conf, X.t_conf);
+        app(t_gi, X.gd.t_gap_init); app(t_ge, X.gd.t_gap_extn);
+      }
+      L.sim.q_prof.aa = q_aa.data(); L.sim.q_prof.sse = q_sse.data(); L.sim.q_prof.conf = q_conf.data();
+      L.sim.t_prof.aa = t_aa.data(); L.sim.t_prof.sse = t_sse.data(); L.sim.t_prof.conf = t_conf.data();
+      L.gap.t_gap_init = t_gi.data(); L.gap.t_gap_extn = t_ge.data();
+      L.gap.dp_local = islocal ? 2 : 1;
+      aln::check(aln_batch_dp(batch_, &L.sim, &L.gap, (int)direction, ALN_DP_AUTO, 0), aln::default_ctx());
+      return;
+    }
     if (L.gap.model != ALN_GAP_AFFINE_CONST)
       throw std::string("DPMatrixSet: this evaluator's gap functions are lowered per pair; build DPMatrix objects");
     if (L.sim.kind == ALN_SIM_MATRIX) {                     // a plane per pair, as DPMatrix::build makes them one at a time
@@ -135,7 +158,7 @@ class DPMatrixSet {
       L.sim.planes = planes.data();
       L.sim.plane_off = plane_off.data();
     } else if (L.sim.kind != ALN_SIM_SUBMATRIX) {
-      throw std::string("DPMatrixSet: profile evaluators are lowered per pair; build DPMatrix objects");
+      throw std::string("DPMatrixSet: this evaluator's similarity source is lowered per pair; build DPMatrix objects");
     }
     L.gap.dp_local = islocal ? 2 : 1;                       // the constructor's `type` decides the clipping (dpmatrix.h:155)
     aln::check(aln_batch_dp(batch_, &L.sim, &L.gap, (int)direction, ALN_DP_AUTO, 0), aln::default_ctx());

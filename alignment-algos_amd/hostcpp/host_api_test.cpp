@@ -199,6 +199,36 @@ int main(int argc, char** argv) {
       tri("dist", t.distance); tri("vv_gi", ev.vv_gi); tri("vv_ge", ev.vv_ge); tri("vv_cd", ev.vv_cd);
       return 0;
     }
+    if (cmd == "setprofile") {  // setprofile <mode> <q1.hmap> <t1.hmap> [<q2.hmap> <t2.hmap> ...]: Hmap2Eval pairs in one launch
+      Gn2Params p;
+      p.align_type = (align_t)atoi(argv[2]);
+      std::vector<HMAPSequence*> qo;
+      std::vector<SMAPSequence*> to;
+      std::vector<const HMAPSequence*> qv;
+      std::vector<const SMAPSequence*> tv;
+      for (int a = 3; a + 1 < argc; a += 2) { qo.push_back(new HMAPSequence(argv[a])); to.push_back(new SMAPSequence(argv[a + 1])); qv.push_back(qo.back()); tv.push_back(to.back()); }
+      Hmap2Eval ev(p);
+      DPMatrixSet<HMAPSequence, SMAPSequence, Hmap2Eval> set(qv, tv, ev, fwd, p.align_type);
+      int bad = 0;
+      for (size_t k = 0; k < set.size(); ++k) {
+        DPMatrix<HMAPSequence, SMAPSequence, Hmap2Eval> dpm(*qv[k], *tv[k], ev, fwd, p.align_type);
+        const int Q = dpm.getQuerySize(), T = dpm.getTemplateSize();
+        for (int i = 0; i < Q; ++i)
+          for (int j = 0; j < T; ++j) {
+            const DPCell* a = dpm.getCell(i, j);
+            const DPCell b = set.getCell(k, i, j);
+            if (fbits(a->score) != fbits(b.score) || a->prev_query_idx != b.prev_query_idx || a->prev_template_idx != b.prev_template_idx) ++bad;
+          }
+        if (fbits(dpm.getSim(Q / 2, T / 2)) != fbits(set.getSim(k, Q / 2, T / 2))) ++bad;
+        Optimal<HMAPSequence, SMAPSequence, Hmap2Eval> opt(p.align_type);
+        AlignmentSet<HMAPSequence, SMAPSequence, Hmap2Eval> as(dpm, opt);
+        DPMatrixSet<HMAPSequence, SMAPSequence, Hmap2Eval>::Alignment o = set.optimal(k);
+        if (fbits(o.score) != fbits(as[0].score) || o.size() != as[0].size() || !std::equal(o.begin(), o.end(), as[0].begin())) ++bad;
+      }
+      printf("SET profile pairs %d mismatches %d\n%s\n", (int)set.size(), bad, bad ? "SET FAILED" : "SET OK");
+      for (size_t k = 0; k < qo.size(); ++k) { delete qo[k]; delete to[k]; }
+      return 0;
+    }
     if (cmd == "set") {         // set <mode> <gi> <ge> <blosum> <q1> <t1> [<q2> <t2> ...]
       AliParams p;
       p.align_type = (align_t)atoi(argv[2]);

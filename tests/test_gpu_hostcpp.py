@@ -170,3 +170,18 @@ def test_dpmatrix_set_equals_one_dpmatrix_per_pair(mode, gi, ge):
     assert r.returncode == 0, r.stderr
     assert "SET OK" in r.stdout and "mismatches 0" in r.stdout and "SET tables refused" in r.stdout, r.stdout + r.stderr
     assert r.stdout.count("mismatches 0") == 2, r.stdout
+
+
+@pytest.mark.parametrize("mode", [1, 4])
+def test_dpmatrix_set_of_profile_pairs(mode, tmp_path):
+    """DPMatrixSet with Hmap2Eval: three profile pairs of different sizes pooled into one resident batch (similarity, z-normalisation
+    and the position-minimum gap DP on the device for all of them) against one DPMatrix per pair: every cell, a similarity probe,
+    Optimal's alignment."""
+    args = ["setprofile", mode]
+    for k, (ql, tl) in enumerate([(37, 52), (80, 61), (23, 140)]):
+        write_hmap(str(tmp_path / ("q%d.hmap" % k)), "query%d" % k, random_profile(94000 + k, ql))
+        write_hmap(str(tmp_path / ("t%d.hmap" % k)), "templ%d" % k, random_profile(95000 + k, tl))
+        args += [tmp_path / ("q%d.hmap" % k), tmp_path / ("t%d.hmap" % k)]
+    r = subprocess.run([EXE] + [str(a) for a in args], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "SET OK" in r.stdout and "mismatches 0" in r.stdout, r.stdout + r.stderr
