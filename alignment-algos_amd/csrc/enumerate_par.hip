@@ -317,6 +317,53 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
         // wave's LDS arrays, libstdc++'s sort / partial_sort on them (enum_sort.h, one lane: the order of equal scores is observable),
         // the k_limit best become the node's operations — the best keeps (about) the node's limit, the others get half of it.
         int n = 0;
+        auto collect = [&](bool ok, float sum, int idx) {                   // one 64-candidate group, appended in lane order
+          const unsigned long long m = __ballot(ok);
+          if (m) {
+            const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+            if (ok && pos < kKsCap) { ks_sc[pos] = sum; ks_ix[pos] = idx; }
+            n += __popcll(m);
+          }
+        };
+        if (e.model == ALN_GAP_AFFINE_CONST && a.rowmax && Q <= 4096 && T <= 4096 && e.gi >= 0.f && e.ge >= 0.f) {
+          // only the 64-cell blocks whose maximum can pass (see the pruned scan below), in the reference's candidate order
+          const bool kfdel = (e.align_type == ALN_LOCAL || e.align_type == ALN_SEMI_LOCAL || e.align_type == ALN_LOCAL_GLOBAL);
+          const bool kfins = (e.align_type == ALN_LOCAL || e.align_type == ALN_SEMI_LOCAL || e.align_type == ALN_GLOBAL_LOCAL);
+          const float* rmax = a.rowmax + ((size_t)(pair - a.bm_pair0) * a.bm_rows + (size_t)(q0 - 1)) * a.nbt;
+          const float* cmax = a.colmax + ((size_t)(pair - a.bm_pair0) * a.bm_cols + (size_t)(t0 - 1)) * a.nbq;
+          bool pass_d = false, pass_i = false;
+          {
+            const int lo = lane * 64 > 1 ? lane * 64 : 1;
+            int hi = lane * 64 + 63; hi = hi < t0 - 2 ? hi : t0 - 2;
+            if (lo <= hi) {
+              const int len = t0 - hi - 1;
+              const float g = (len < 1 || (kfdel && t0 == T - 1)) ? 0.f : e.gi + e.ge * (float)(len - 1);
+              pass_d = (rmax[lane] + r) - g > thr;
+            }
+            int hq = lane * 64 + 63; hq = hq < q0 - 2 ? hq : q0 - 2;
+            if (lo <= hq) {
+              const int len = q0 - hq - 1;
+              const float g = (len < 1 || (kfins && q0 == Q - 1)) ? 0.f : e.gi + e.ge * (float)(len - 1);
+              pass_i = (cmax[lane] + r) - g > thr;
+            }
+          }
+          const unsigned long long md = __ballot(pass_d), mi = __ballot(pass_i);
+          { const float sum = HV(q0 - 1, t0 - 1) + r; collect(lane == 0 && sum > thr, sum, 0); }
+          for (unsigned long long mm = md; mm; ) {
+            const int blk = 63 - __builtin_clzll(mm); mm &= ~(1ull << blk);
+            const int pt = blk * 64 + 63 - lane;
+            const bool in = pt >= 1 && pt <= t0 - 2;
+            const float sum = in ? HV(q0 - 1, pt) + r - dev_deletion(e, pt, t0) : 0.f;
+            collect(in && sum > thr, sum, t0 - 1 - pt);
+          }
+          for (unsigned long long mm = mi; mm; ) {
+            const int blk = 63 - __builtin_clzll(mm); mm &= ~(1ull << blk);
+            const int pq = blk * 64 + 63 - lane;
+            const bool in = pq >= 1 && pq <= q0 - 2;
+            const float sum = in ? HV(pq, t0 - 1) + r - dev_insertion(e, pq, q0, t0 - 1, t0) : 0.f;
+            collect(in && sum > thr, sum, ndel + 1 + (q0 - 2 - pq));
+          }
+        } else
         for (int base = 0; base < ncand; base += 64) {
           const int idx = base + lane;
           bool ok = false; float sum = 0.f;
@@ -326,12 +373,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
             else { const int pq = q0 - 2 - (idx - ndel - 1); sum = HV(pq, t0 - 1) + r - dev_insertion(e, pq, q0, t0 - 1, t0); }
             ok = sum > thr;
           }
-          const unsigned long long m = __ballot(ok);
-          if (m) {
-            const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-            if (ok && pos < kKsCap) { ks_sc[pos] = sum; ks_ix[pos] = idx; }
-            n += __popcll(m);
-          }
+          collect(ok, sum, idx);
         }
         if (n > kKsCap) { fail(kParSerial); break; }                        // more candidates than this kernel keeps per wave
         if (n == 0) { is_branch = false; force = true; klimit = 1; continue; }   // kscw.h:222-228: op(1, q0, t0, k0), forced
