@@ -289,8 +289,19 @@ int upload_simplanes(aln_batch* b, const aln_sim* sim, bool* integral) {
   return ALN_OK;
 }
 
+// everything upload_tgaps will dereference, checked before a single resident table is touched
+int check_gap_arrays(const aln_gap* gap) {
+  if (gap->model == ALN_GAP_AFFINE_CONST) return ALN_OK;
+  if (gap->model != ALN_GAP_TABLES && (!gap->t_gap_init || !gap->t_gap_extn)) return ALN_E_ARG;
+  if (gap->model == ALN_GAP_DEL_TABLE_INS_TPOS && !gap->t_gap_cn) return ALN_E_ARG;
+  if ((gap->model == ALN_GAP_DEL_TABLE_INS_TPOS || gap->model == ALN_GAP_TABLES) && (!gap->del_table || !gap->del_table_off)) return ALN_E_ARG;
+  if (gap->model == ALN_GAP_TABLES && (!gap->ins_tables || !gap->ins_table_off)) return ALN_E_ARG;
+  return ALN_OK;
+}
+
 int upload_tgaps(aln_batch* b, const aln_gap* gap) {
   aln_ctx* ctx = b->ctx;
+  { const int rc = check_gap_arrays(gap); if (rc) return rc; }
   if (!b->d_tgi) { int rc = dalloc(ctx, &b->d_tgi, (size_t)std::max<int64_t>(b->t_total, 1)); if (rc) return rc; }
   if (!b->d_tge) { int rc = dalloc(ctx, &b->d_tge, (size_t)std::max<int64_t>(b->t_total, 1)); if (rc) return rc; }
   if (gap->model != ALN_GAP_TABLES) {             // per-position coefficient arrays (the table model has none)
@@ -439,7 +450,16 @@ int aln_batch_set_gap(aln_batch* b, const aln_gap* gap) {
   ALN_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (!valid_align_type(gap->align_type)) return ALN_E_GAPSTYLE;
   if (gap->model != ALN_GAP_AFFINE_CONST && gap->model != ALN_GAP_AFFINE_TPOS_MIN && gap->model != ALN_GAP_DEL_TABLE_INS_TPOS && gap->model != ALN_GAP_TABLES) return ALN_E_ARG;
+  { const int rc = check_gap_arrays(gap); if (rc) return rc; }     // a bad description leaves the batch as it was
   ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));           // nothing may still read the tables that are replaced
+  if (gap->model != ALN_GAP_AFFINE_CONST) {
+    const int rc = upload_tgaps(b, gap);
+    if (rc) {                       // a device error half way: resident tables may be gone — the batch needs a full aln_batch_dp again
+      b->have_dp = false;
+      return rc;
+    }
+  }
+  // the upload succeeded: commit the description
   b->gap = *gap;
   b->islocal = gap->dp_local == 0 ? (gap->align_type == ALN_LOCAL) : (gap->dp_local == 2);
   b->gapdev.model = gap->model;
@@ -447,7 +467,6 @@ int aln_batch_set_gap(aln_batch* b, const aln_gap* gap) {
   b->gapdev.gi = gap->gap_init; b->gapdev.ge = gap->gap_extn;
   b->gapdev.free_del = (gap->align_type == ALN_LOCAL || gap->align_type == ALN_SEMI_LOCAL || gap->align_type == ALN_LOCAL_GLOBAL);
   b->gapdev.free_ins = (gap->align_type == ALN_LOCAL || gap->align_type == ALN_SEMI_LOCAL || gap->align_type == ALN_GLOBAL_LOCAL);
-  if (gap->model != ALN_GAP_AFFINE_CONST) { const int rc = upload_tgaps(b, gap); if (rc) return rc; }
   b->gap.t_gap_init = nullptr; b->gap.t_gap_extn = nullptr;        // host pointers are not retained
   return ALN_OK;
 }

@@ -29,6 +29,7 @@
 
 namespace aln {
 
+constexpr int kNotReading = 0x7FFFFFFF;   // s_reading: this wave holds no unread ticket
 constexpr int kKsCap = 256;      // KSCW in this kernel: candidates of one branch node that may pass the threshold (more: the one-wave kernel)
 
 __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __restrict__ pairs, int pair, EvalDev proto,
@@ -41,6 +42,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
   __shared__ unsigned s_nodes, s_slots;
   __shared__ unsigned long long s_alloc;  // node allocator of this pair: current chunk << 32 | nodes used in it
   __shared__ int s_lock;
+  __shared__ int s_reading[16];           // per wave: the ticket it is taking / has taken and not yet read (kNotReading otherwise)
   __shared__ uint16_t s_chunk[16][136];   // per wave: the blocks of a branch node's candidate row / column that can hold a passing candidate
   {
     const size_t bi = blockIdx.x;
@@ -101,6 +103,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
 
   const uint32_t qcap = a.ali_cap;                    // ring of task records (every pending task owns a distinct slot, so <= ali_cap pend)
   const uint32_t qmargin = qcap / 4u < 2048u ? qcap / 4u : 2048u;
+  if (threadIdx.x < 16) s_reading[threadIdx.x] = kNotReading;
   if (threadIdx.x == 0) {
     s_head = 0; s_tail = 1; s_done = 0; s_status = 0; s_nodes = 0u; s_lock = 0;
     s_slots = (unsigned)a.first_slot + 1u;             // as.push_back(SingleAlignment())  cw.h:82 / ucw.h:78
@@ -166,8 +169,12 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
         const int h = __hip_atomic_load(&s_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const int t = __hip_atomic_load(&s_tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (h < t) {
+          // announce the ticket BEFORE taking it (LDS operations of one wave are served in order): a pusher that sees s_head
+          // beyond h also sees the announcement, so min(s_head, announcements) never passes an unread record
+          __hip_atomic_store(&s_reading[w], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           int expect = h;
           if (__hip_atomic_compare_exchange_strong(&s_head, &expect, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { tkt = h; break; }
+          __hip_atomic_store(&s_reading[w], kNotReading, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // lost the race for h
           continue;
         }
         if (d == t) break;                               // nothing pending, nothing running
@@ -193,6 +200,7 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
       const uint32_t v = lane < 7 ? ld_w(tk + lane) : 0u;
       tw0 = (uint32_t)__shfl((int)v, 0); tw1 = (uint32_t)__shfl((int)v, 1); tw2 = (uint32_t)__shfl((int)v, 2);
       tw3 = (uint32_t)__shfl((int)v, 3); tw4 = (uint32_t)__shfl((int)v, 4); tw6 = (uint32_t)__shfl((int)v, 6);
+      if (lane == 0) __hip_atomic_store(&s_reading[w], kNotReading, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // the record is in registers
     }
 
     // ---- one task: opt_path / branch of ONE alignment slot until its branch node has spawned its children ---------------
@@ -284,9 +292,16 @@ __global__ __launch_bounds__(1024) void enumerate_par_kernel(const PairDesc* __r
         }
         bt = (uint32_t)__shfl((int)bt, 0); bs = (uint32_t)__shfl((int)bs, 0);
         if (nnew && bs + (uint32_t)nnew > a.user_limit) { fail(kParSerial); dead = true; return; }   // the serial order decides what user_limit cuts
-        const uint32_t pending = bt + (uint32_t)n - (uint32_t)__hip_atomic_load(&s_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        // (every wave of the workgroup may be pushing 64 records at this moment: keep that much of the ring free, so that no
-        // record is overwritten before the wave that took its ticket has read it)
+        // floor = the oldest ticket whose record may still be unread: s_head (read first), lowered by every wave's announcement
+        int floor_t = __hip_atomic_load(&s_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        {
+          int mine = lane < 16 ? __hip_atomic_load(&s_reading[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : kNotReading;
+          for (int o = 8; o; o >>= 1) { const int other = __shfl_xor(mine, o); mine = other < mine ? other : mine; }
+          mine = __shfl(mine, 0);
+          floor_t = mine < floor_t ? mine : floor_t;
+        }
+        const uint32_t pending = bt + (uint32_t)n - (uint32_t)floor_t;
+        // (every wave of the workgroup may be pushing 64 records at this moment: keep that much of the ring free as well)
         if (pending + qmargin > qcap || bs + (uint32_t)nnew > a.ali_cap) {
           fail(ALN_E_OVERFLOW); dead = true; return;
         }

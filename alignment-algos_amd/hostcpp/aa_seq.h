@@ -3,6 +3,8 @@
 #define ALN_HOST_AA_SEQ_H
 #include <string>
 #include "sequence.h"
+// standard headers the reference's aa_seq.h hands on to its includers
+#include <vector>
 
 class AASequence : public Sequence<SequenceElem*> {
  public:

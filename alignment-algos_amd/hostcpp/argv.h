@@ -5,6 +5,9 @@
 #include <string>
 #include <vector>
 #include "pstore.h"
+// standard headers the reference's argv.h hands on to its includers
+#include <sstream>
+using namespace std;   // as the reference's argv.h does at header scope: sources written against it name string, vector, cerr ... unqualified
 
 class Argv : public ParamStore {
  public:

@@ -7,6 +7,10 @@
 #ifndef ALN_HOST_CRCW_H
 #define ALN_HOST_CRCW_H
 #include "cw.h"
+// standard headers the reference's crcw.h hands on to its includers
+#include <string>
+#include <iomanip>
+using namespace std;   // as the reference's crcw.h does at header scope: sources written against it name string, vector, cerr ... unqualified
 
 template <class S1, class S2, class Etype>
 class CRConstrainedNearOptimal : public Enumerator<S1, S2, Etype> {

@@ -10,6 +10,10 @@
 #include "enumerator.h"
 #include "noalib.h"
 #include "sflags.h"
+// standard headers the reference's cw.h hands on to its includers
+#include <algorithm>
+#include <string>
+using namespace std;   // as the reference's cw.h does at header scope: sources written against it name string, vector, cerr ... unqualified
 
 namespace aln {
 template <class S1, class S2, class Etype>

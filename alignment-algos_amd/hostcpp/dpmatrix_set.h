@@ -118,7 +118,9 @@ class DPMatrixSet {
     std::vector<int64_t> plane_off;
     std::vector<float> planes;
     if (n == 0) return;
-    for (size_t p = 0; p < n; ++p) evaluator->pre_calculate(*qs[p], *ts[p]);                 // dpmatrix.h:298
+    // pre_calculate belongs to ONE pair: the reference calls it right before building that pair (dpmatrix.h:298), so an
+    // evaluator may keep per-pair state in itself.  Every lowering below is therefore preceded by its own pair's call.
+    evaluator->pre_calculate(*qs[0], *ts[0]);
     aln::Lowering<S1, S2, Etype>::lower(*qs[0], *ts[0], evaluator->Derived(), L);
     std::vector<float> q_aa, q_sse, q_conf, t_aa, t_sse, t_conf, t_gi, t_ge;    // profile pools (Hmap2Eval / HMAPaliEval)
     if (L.sim.kind == ALN_SIM_HMAP2 && L.gap.model == ALN_GAP_AFFINE_TPOS_MIN) {
@@ -126,7 +128,10 @@ class DPMatrixSet {
       auto app = [](std::vector<float>& dst, const std::vector<float>& src) { dst.insert(dst.end(), src.begin(), src.end()); };
       for (size_t p = 0; p < n; ++p) {
         aln::Lowered Lp;
-        if (p) aln::Lowering<S1, S2, Etype>::lower(*qs[p], *ts[p], evaluator->Derived(), Lp);
+        if (p) {
+          evaluator->pre_calculate(*qs[p], *ts[p]);
+          aln::Lowering<S1, S2, Etype>::lower(*qs[p], *ts[p], evaluator->Derived(), Lp);
+        }
         const aln::Lowered& X = p ? Lp : L;
         if (X.sim.kind != ALN_SIM_HMAP2 || X.sim.alpha != L.sim.alpha || X.sim.zero_shift != L.sim.zero_shift || X.gap.align_type != L.gap.align_type)
           throw std::string("DPMatrixSet: the evaluator's parameters differ from pair to pair; build DPMatrix objects");
@@ -148,6 +153,7 @@ class DPMatrixSet {
       planes = L.plane;
       for (size_t p = 1; p < n; ++p) {
         aln::Lowered Lp;
+        evaluator->pre_calculate(*qs[p], *ts[p]);
         aln::Lowering<S1, S2, Etype>::lower(*qs[p], *ts[p], evaluator->Derived(), Lp);
         if (Lp.gap.model != ALN_GAP_AFFINE_CONST || Lp.gap.gap_init != L.gap.gap_init || Lp.gap.gap_extn != L.gap.gap_extn ||
             Lp.gap.align_type != L.gap.align_type)
@@ -159,6 +165,8 @@ class DPMatrixSet {
       L.sim.plane_off = plane_off.data();
     } else if (L.sim.kind != ALN_SIM_SUBMATRIX) {
       throw std::string("DPMatrixSet: this evaluator's similarity source is lowered per pair; build DPMatrix objects");
+    } else {
+      for (size_t p = 1; p < n; ++p) evaluator->pre_calculate(*qs[p], *ts[p]);   // one table for all pairs: the hook still runs once per pair
     }
     L.gap.dp_local = islocal ? 2 : 1;                       // the constructor's `type` decides the clipping (dpmatrix.h:155)
     aln::check(aln_batch_dp(batch_, &L.sim, &L.gap, (int)direction, ALN_DP_AUTO, 0), aln::default_ctx());

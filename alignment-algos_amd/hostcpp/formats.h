@@ -6,6 +6,9 @@
 #include <string>
 #include "alignment.h"
 #include "gstrings.h"
+// standard headers the reference's formats.h hands on to its includers
+#include <iostream>
+#include <sstream>
 
 struct Formats {
   struct FastaOut { FastaOut(int len = 60) : line_length(len) {} int line_length; };

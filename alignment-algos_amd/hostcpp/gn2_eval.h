@@ -54,64 +54,69 @@ class Gn2Eval : public Evaluator<HMAPSequence, SMAPSequence, Gn2Eval> {
  public:
   explicit Gn2Eval(Gn2Params& p) : params(&p) {}
 
-  float similarity(const HMAPSequence& q, const SMAPSequence& t, int q_pos, int t_pos) const {
-    float ip = norm_dot(q[q_pos]->aa_profile, t[t_pos]->aa_profile);
-    unsigned int lods_idx = t[t_pos]->lods_type * 12 + q[q_pos]->lods_type;
-    float log_aa = 0.543f / (2.85f - std::exp(ip)) - 0.738f;
-    float log_ss = params->ss_lods[lods_idx];
-    float log_cn = 2.f * t.weighted_contact_number[t_pos] - 0.9f;
-    float log_hp = std::exp(std::exp(-std::abs(q[q_pos]->hydropathy - t[t_pos]->hydropathy)) *
-                            (0.75f + 0.3f * std::abs(t[t_pos]->hydropathy - 0.22f))) - 1.8f;
-    float sim = params->gn2_shift + params->aa_weight * log_aa + params->ss_weight * log_ss + params->cn_weight * log_cn +
-                params->hp_weight * log_hp;
-    return sim;
+  // Score of one cell = shift + Σ weight·term over four log-odds-like terms, summed left to right in fp32 (gn2_eval.h:71-98):
+  //   residues   0.543 / (2.85 − e^cos) − 0.738, cos = normalised dot of the two 20-vectors
+  //   sec.struct a 12×12 table entry picked by the two positions' lods types
+  //   burial     2·(template contact number) − 0.9
+  //   hydropathy e^( e^(−|hq − ht|) · (0.75 + 0.3·|ht − 0.22|) ) − 1.8
+  float similarity(const HMAPSequence& q, const SMAPSequence& t, int qi, int ti) const {
+    const HMAPSequence::value_type& qe = q[qi];
+    const SMAPSequence::value_type& te = t[ti];
+    const float term_res = 0.543f / (2.85f - std::exp(norm_dot(qe->aa_profile, te->aa_profile))) - 0.738f;
+    const float term_sse = params->ss_lods[te->lods_type * 12 + qe->lods_type];
+    const float term_bur = 2.f * t.weighted_contact_number[ti] - 0.9f;
+    const float term_hyd = std::exp(std::exp(-std::abs(qe->hydropathy - te->hydropathy)) * (0.75f + 0.3f * std::abs(te->hydropathy - 0.22f))) - 1.8f;
+    float total = params->gn2_shift;
+    total += params->aa_weight * term_res;
+    total += params->ss_weight * term_sse;
+    total += params->cn_weight * term_bur;
+    total += params->hp_weight * term_hyd;
+    return total;
   }
-  float deletion(const HMAPSequence&, const SMAPSequence& t, int, int, int t_pos1, int t_pos2) const {
-    int di = t_pos2 - t_pos1;
-    if (di < 2) return 0;
-    int p1 = t_pos1, p2 = t_pos2 - 2;
-    float GP = 8100.f;
-    if (t.distance[p2][p1] < 18.f) GP = vv_gi[p2][p1] + vv_ge[p2][p1] * (di - 2) + vv_cd[p2][p1];
-    switch (params->align_type) {
-      case global: case global_local: return GP;
-      case local: case semi_local: case local_global:
-        if (t[t_pos1]->isHead() || t[t_pos2]->isTail()) return 0;
-        return GP;
-      default: throw std::string("Invalid align_type");
-    }
+  // Skipping template positions t1+1..t2-1 (gn2_eval.h:100-131): tabulated per (t2-2, t1) — affine part + distance/H-bond part —
+  // unless the two flanks are 18 Å or more apart (then a prohibitive 8100); free where the align type frees template ends.
+  float deletion(const HMAPSequence&, const SMAPSequence& t, int, int, int t1, int t2) const {
+    const int hop = t2 - t1;
+    if (hop < 2) return 0;
+    check_type();
+    if (template_ends_free() && (t[t1]->isHead() || t[t2]->isTail())) return 0;
+    const int row = t2 - 2;
+    if (!(t.distance[row][t1] < 18.f)) return 8100.f;
+    return vv_gi[row][t1] + vv_ge[row][t1] * (hop - 2) + vv_cd[row][t1];
   }
-  float insertion(const HMAPSequence& q, const SMAPSequence&, int q_pos1, int q_pos2, int t_pos1, int) const {
-    int di = q_pos2 - q_pos1;
-    if (di < 2) return 0;
-    float GP = v_gi[t_pos1] + v_ge[t_pos1] * (di - 2) + v_cn[t_pos1];
-    switch (params->align_type) {
-      case global: case local_global: return GP;
-      case local: case semi_local: case global_local:
-        if (q[q_pos1]->isHead() || q[q_pos2]->isTail()) return 0;
-        return GP;
-      default: throw std::string("Invalid align_type");
-    }
+  // Skipping query positions q1+1..q2-1 after template position t1 (gn2_eval.h:133-158): affine part + burial part of t1
+  float insertion(const HMAPSequence& q, const SMAPSequence&, int q1, int q2, int t1, int) const {
+    const int hop = q2 - q1;
+    if (hop < 2) return 0;
+    check_type();
+    if (query_ends_free() && (q[q1]->isHead() || q[q2]->isTail())) return 0;
+    return v_gi[t1] + v_ge[t1] * (hop - 2) + v_cn[t1];
   }
+  // Tables per template (gn2_eval.cpp:113-158).  Between positions i and i+1: gap constants blended by the larger coil
+  // probability of the two, and ic_weight·(1.693 − ln(sum of their contact numbers)).  Per (i-2, j), j < i-1: coil constants
+  // unless both flanks lie in the same secondary-structure element, e^(distance − dd_constr), plus hb_weight·broken H-bonds
+  // where a gap is allowed.
   void pre_calculate(const HMAPSequence&, const SMAPSequence& templ) const {
     const unsigned int n = templ.seq_length;
-    v_gi.resize(n + 1); v_ge.resize(n + 1); v_cn.resize(n + 1);
+    v_gi.assign(n + 1, 0.f); v_ge.assign(n + 1, 0.f); v_cn.assign(n + 1, 0.f);
     for (unsigned int i = 0; i <= n; ++i) {
-      float v_coil = std::max(templ[i]->p_coil(), templ[i + 1]->p_coil());
-      v_gi[i] = v_coil * params->gap_init_coil + (1 - v_coil) * params->gap_init_ss;
-      v_ge[i] = v_coil * params->gap_extn_coil + (1 - v_coil) * params->gap_extn_ss;
-      float cn = templ.weighted_contact_number[i] + templ.weighted_contact_number[i + 1];
-      v_cn[i] = params->ic_weight * (1.693f - std::log(cn));
+      const float coil = std::max(templ[i]->p_coil(), templ[i + 1]->p_coil());
+      v_gi[i] = blend(coil, params->gap_init_coil, params->gap_init_ss);
+      v_ge[i] = blend(coil, params->gap_extn_coil, params->gap_extn_ss);
+      v_cn[i] = params->ic_weight * (1.693f - std::log(templ.weighted_contact_number[i] + templ.weighted_contact_number[i + 1]));
     }
-    vv_gi.resize(n); vv_ge.resize(n); vv_cd.resize(n);
-    for (unsigned int i = 2; i < n + 2; ++i) {
-      vv_gi[i - 2].resize(i - 1); vv_ge[i - 2].resize(i - 1); vv_cd[i - 2].resize(i - 1);
-      for (unsigned int j = 0; j < i - 1; ++j) {
-        float v_allow = 1;
-        if (templ[i]->rdata.isse == templ[j]->rdata.isse && templ[i]->rdata.isse > -1) v_allow = 0;
-        vv_gi[i - 2][j] = v_allow * params->gap_init_coil + (1.f - v_allow) * params->gap_init_ss;
-        vv_ge[i - 2][j] = v_allow * params->gap_extn_coil + (1.f - v_allow) * params->gap_extn_ss;
-        vv_cd[i - 2][j] = std::exp(templ.distance[i - 2][j] - params->dd_constr);
-        vv_cd[i - 2][j] += v_allow * params->hb_weight * templ.brokenhb[i - 2][j];
+    vv_gi.assign(n, std::vector<float>()); vv_ge.assign(n, std::vector<float>()); vv_cd.assign(n, std::vector<float>());
+    for (unsigned int row = 0; row < n; ++row) {
+      const unsigned int i = row + 2;
+      std::vector<float> &gi = vv_gi[row], &ge = vv_ge[row], &cd = vv_cd[row];
+      gi.resize(i - 1); ge.resize(i - 1); cd.resize(i - 1);
+      for (unsigned int j = 0; j + 1 < i; ++j) {
+        const int elem = templ[i]->rdata.isse;
+        const float open = (elem > -1 && elem == templ[j]->rdata.isse) ? 0.f : 1.f;
+        gi[j] = blend(open, params->gap_init_coil, params->gap_init_ss);
+        ge[j] = blend(open, params->gap_extn_coil, params->gap_extn_ss);
+        cd[j] = std::exp(templ.distance[row][j] - params->dd_constr);
+        cd[j] += open * params->hb_weight * templ.brokenhb[row][j];
       }
     }
   }
@@ -122,6 +127,10 @@ class Gn2Eval : public Evaluator<HMAPSequence, SMAPSequence, Gn2Eval> {
   mutable std::vector<std::vector<float> > vv_gi, vv_ge, vv_cd;
 
  private:
+  static float blend(float w, float at_one, float at_zero) { return w * at_one + (1.f - w) * at_zero; }
+  void check_type() const { if (params->align_type < 0 || params->align_type > 4) throw std::string("Invalid align_type"); }
+  bool template_ends_free() const { return params->align_type == local || params->align_type == semi_local || params->align_type == local_global; }
+  bool query_ends_free() const { return params->align_type == local || params->align_type == semi_local || params->align_type == global_local; }
   static float norm_dot(const std::valarray<float>& a, const std::valarray<float>& b) {   // hmath.h:27-40
     float res = 0.f, sa = 0.f, sb = 0.f;
     for (size_t k = 0; k < a.size(); ++k) { float p = a[k] * b[k]; res += p; }

@@ -8,6 +8,11 @@
 #include <valarray>
 #include <vector>
 #include "alignment.h"
+// standard headers the reference's gstrings.h hands on to its includers
+#include <algorithm>
+#include <cassert>
+#include <cctype>
+using namespace std;   // as the reference's gstrings.h does at header scope: sources written against it name string, vector, cerr ... unqualified
 
 class SequenceGaps {
  public:

@@ -90,6 +90,42 @@ class HalfBlosumEval : public Evaluator<S1, S2, HalfBlosumEval<S1, S2> > {
   const SubstitutionMatrix* sub;
 };
 
+// A plugin that keeps per-pair state IN ITSELF: pre_calculate stores a shift derived from the two lengths, similarity() uses
+// it.  The reference calls pre_calculate right before it builds a pair (dpmatrix.h:298); a set that called it for all pairs
+// first would build every pair but the last with the wrong shift.
+template <class S1, class S2>
+class PairShiftEval : public Evaluator<S1, S2, PairShiftEval<S1, S2> > {
+ public:
+  PairShiftEval(const AliParams& p, const SubstitutionMatrix& m) : params(&p), sub(&m), shift(-100.f) {}
+  float similarity(const S1& q, const S2& t, int qi, int ti) const {
+    if (q[qi]->isHead() || q[qi]->isTail() || t[ti]->isHead() || t[ti]->isTail()) return 0.f;
+    return sub->score(q[qi]->olc, t[ti]->olc) + shift;
+  }
+  float deletion(const S1&, const S2& t, int, int, int t1, int t2) const {
+    const int len = t2 - t1 - 1;
+    if (len < 1) return 0.f;
+    if (free_end() && (t[t1]->isHead() || t[t2]->isTail())) return 0.f;
+    return params->gap_init_penalty + params->gap_extn_penalty * (float)(len - 1);
+  }
+  float insertion(const S1& q, const S2&, int q1, int q2, int, int) const {
+    const int len = q2 - q1 - 1;
+    if (len < 1) return 0.f;
+    if (free_end() && (q[q1]->isHead() || q[q2]->isTail())) return 0.f;
+    return params->gap_init_penalty + params->gap_extn_penalty * (float)(len - 1);
+  }
+  void pre_calculate(const S1& q, const S2& t) const { shift = 0.125f * (float)((q.size() * 7 + t.size() * 3) % 9) - 0.5f; }
+  void post_process(SimilarityMatrix&) const {}
+  void aln_describe_gaps(const S1&, const S2&, aln::GapDescription& g) const {
+    g.model = ALN_GAP_AFFINE_CONST; g.align_type = params->align_type;
+    g.gap_init = params->gap_init_penalty; g.gap_extn = params->gap_extn_penalty;
+  }
+ private:
+  bool free_end() const { return params->align_type == local || params->align_type == semi_local; }
+  const AliParams* params;
+  const SubstitutionMatrix* sub;
+  mutable float shift;
+};
+
 // DPMatrixSet against one DPMatrix per pair: every cell, the Optimal alignment, the ConstrainedNearOptimal set
 template <class Eval>
 static int compare_set(const char* tag, const std::vector<const AASequence*>& qv, const std::vector<const AASequence*>& tv, const Eval& ev, align_t type) {
@@ -248,6 +284,8 @@ int main(int argc, char** argv) {
       HalfBlosumEval<AASequence, AASequence> hv(p, blosum);
       int bad = compare_set("aasub", qv, tv, ev, p.align_type);
       bad += compare_set("plugin", qv, tv, hv, p.align_type);
+      PairShiftEval<AASequence, AASequence> pv(p, blosum);
+      bad += compare_set("pairstate", qv, tv, pv, p.align_type);
       try {                       // an evaluator whose gap functions are tabulated per pair is refused, loudly
         SqrtGapEval<AASequence, AASequence> sq(p, blosum);
         DPMatrixSet<AASequence, AASequence, SqrtGapEval<AASequence, AASequence> > s2(qv, tv, sq, fwd, p.align_type);

@@ -5,6 +5,9 @@
 #ifndef ALN_HOST_KSCW_H
 #define ALN_HOST_KSCW_H
 #include "cw.h"
+// standard headers the reference's kscw.h hands on to its includers
+#include <string>
+using namespace std;   // as the reference's kscw.h does at header scope: sources written against it name string, vector, cerr ... unqualified
 
 template <class S1, class S2, class Etype>
 class KSConstrainedNearOptimal : public Enumerator<S1, S2, Etype> {

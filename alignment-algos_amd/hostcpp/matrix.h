@@ -2,6 +2,9 @@
 #ifndef ALN_HOST_MATRIX_H
 #define ALN_HOST_MATRIX_H
 #include <vector>
+// standard headers the reference's matrix.h hands on to its includers
+#include <valarray>
+using namespace std;   // as the reference's matrix.h does at header scope: sources written against it name string, vector, cerr ... unqualified
 
 template <class val_t>
 class matrix {

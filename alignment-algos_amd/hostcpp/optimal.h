@@ -6,6 +6,8 @@
 #include "alib.h"
 #include "alignment.h"
 #include "enumerator.h"
+// standard headers the reference's optimal.h hands on to its includers
+#include <iostream>
 
 namespace aln {
 // shared by Optimal / Optimal_Rev / Optimal_Subali: run the device traceback and append the list to `as`

@@ -4,6 +4,8 @@
 #ifndef ALN_HOST_OPTIMAL_REV_H
 #define ALN_HOST_OPTIMAL_REV_H
 #include "optimal.h"
+// standard headers the reference's optimal_rev.h hands on to its includers
+#include <iostream>
 
 template <class S1, class S2, class Etype>
 class Optimal_Rev : public Enumerator<S1, S2, Etype> {

@@ -3,6 +3,8 @@
 #ifndef ALN_HOST_OPTIMAL_SUBALI_H
 #define ALN_HOST_OPTIMAL_SUBALI_H
 #include "optimal.h"
+// standard headers the reference's optimal_subali.h hands on to its includers
+#include <iostream>
 
 template <class S1, class S2, class Etype>
 class Optimal_Subali : public Enumerator<S1, S2, Etype> {

@@ -7,6 +7,7 @@
 #include <map>
 #include <sstream>
 #include <string>
+using namespace std;   // as the reference's pstore.h does at header scope: sources written against it name string, vector, cerr ... unqualified
 
 class ParamStore {
  public:

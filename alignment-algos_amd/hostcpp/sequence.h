@@ -5,6 +5,9 @@
 #define ALN_HOST_SEQUENCE_H
 #include <string>
 #include <vector>
+// standard headers the reference's sequence.h hands on to its includers
+#include <sstream>
+using namespace std;   // as the reference's sequence.h does at header scope: sources written against it name string, vector, cerr ... unqualified
 
 class SequenceElem {
  public:

@@ -5,6 +5,10 @@
 #include <string>
 #include <vector>
 #include "sequence.h"
+// standard headers the reference's sflags.h hands on to its includers
+#include <iostream>
+#include <valarray>
+using namespace std;   // as the reference's sflags.h does at header scope: sources written against it name string, vector, cerr ... unqualified
 
 class SuboptFlags : public Sequence<SequenceElem*> {
  public:

@@ -8,6 +8,9 @@
 #include <ostream>
 #include <string>
 #include <vector>
+// standard headers the reference's submatrix.h hands on to its includers
+#include <map>
+using namespace std;   // as the reference's submatrix.h does at header scope: sources written against it name string, vector, cerr ... unqualified
 
 class SubstitutionMatrix {
  public:

@@ -2,6 +2,9 @@
 #ifndef ALN_HOST_UCW_H
 #define ALN_HOST_UCW_H
 #include "cw.h"
+// standard headers the reference's ucw.h hands on to its includers
+#include <string>
+using namespace std;   // as the reference's ucw.h does at header scope: sources written against it name string, vector, cerr ... unqualified
 
 template <class S1, class S2, class Etype>
 class UnconstrainedNearOptimal : public Enumerator<S1, S2, Etype> {

@@ -159,7 +159,8 @@ def test_dpmatrix_set_equals_one_dpmatrix_per_pair(mode, gi, ge):
     """hostcpp/dpmatrix_set.h (an extension: many DPMatrix builds in one launch) against the one-pair DPMatrix of the reference's
     surface, pair by pair: every cell, Optimal's alignment and score, ConstrainedNearOptimal's sorted set — with
     AASubstitutionEval (codes + table) and with a plugin that names its constant-affine gap model (a SimilarityMatrix plane per
-    pair); an evaluator whose gap functions must be tabulated per pair is refused."""
+    pair), and with a plugin whose similarity depends on a value its own pre_calculate stored for the pair (the hook must run right
+    before each pair is lowered, dpmatrix.h:298); an evaluator whose gap functions must be tabulated per pair is refused."""
     from aln_amd.synth import homolog_pair, random_pair
     pairs = [homolog_pair(93000, 60, sub_rate=0.2, indel=3), random_pair(93001, 30, 45), homolog_pair(93002, 130, sub_rate=0.25, indel=4),
              ("ACDEFG", "ACDFG"), homolog_pair(93003, 300, sub_rate=0.15, indel=5)]
@@ -169,7 +170,7 @@ def test_dpmatrix_set_equals_one_dpmatrix_per_pair(mode, gi, ge):
     r = subprocess.run([EXE] + [str(a) for a in args], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert "SET OK" in r.stdout and "mismatches 0" in r.stdout and "SET tables refused" in r.stdout, r.stdout + r.stderr
-    assert r.stdout.count("mismatches 0") == 2, r.stdout
+    assert r.stdout.count("mismatches 0") == 3 and "SET pairstate" in r.stdout, r.stdout
 
 
 @pytest.mark.parametrize("mode", [1, 4])
