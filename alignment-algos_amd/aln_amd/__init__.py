@@ -68,7 +68,7 @@ EXPORTS = [
     "aln_batch_reevaluate", "aln_batch_dp_kernel_name", "aln_batch_dp_sub", "aln_batch_get_cells", "aln_batch_get_sim",
     "aln_batch_get_corner_scores", "aln_batch_optimal", "aln_batch_optimal_enqueue", "aln_batch_optimal_collect", "aln_batch_optimal_subali", "aln_batch_enumerate", "aln_batch_enumerate_all", "aln_batch_last_enum_ms", "aln_batch_last_enum_usage", "aln_identity",
     "aln_gapped_length", "aln_gapped_strings", "aln_hmap2_gap_arrays", "aln_score_all_vs_all", "aln_batch_last_dp_ms", "aln_batch_dp_ms_history", "aln_batch_dp_algorithmic_bytes", "aln_batch_cells",
-    "aln_batch_optimal_strings", "aln_batch_set_gap", "aln_ctx_set_hint", "aln_ctx_get_hint", "aln_batch_dp_contract_bytes", "aln_batch_plane_bytes_per_cell",
+    "aln_batch_optimal_strings", "aln_batch_optimal_strings_enqueue", "aln_batch_optimal_strings_collect", "aln_batch_last_exact_stats", "aln_batch_set_gap", "aln_ctx_set_hint", "aln_ctx_get_hint", "aln_batch_dp_contract_bytes", "aln_batch_plane_bytes_per_cell",
     "aln_deal_units", "aln_comm_unique_id", "aln_comm_create", "aln_ctx_create_multi", "aln_comm_destroy", "aln_comm_n_ranks",
     "aln_comm_last_error", "aln_gather_scores",
 ]
@@ -137,6 +137,9 @@ def lib():
         L.aln_hmap2_gap_arrays.argtypes = [_fp, C.c_int64, C.c_float, C.c_float, C.c_float, _fp, _fp]
         L.aln_batch_plane_bytes_per_cell.argtypes = [C.c_void_p]
         L.aln_batch_optimal_strings.argtypes = [C.c_void_p, _fp, _fp, _ip, C.c_char_p, C.c_char_p, C.c_int32, _ip]
+        L.aln_batch_last_exact_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.aln_batch_optimal_strings_enqueue.argtypes = [C.c_void_p, C.c_int32]
+        L.aln_batch_optimal_strings_collect.argtypes = [C.c_void_p, _fp, _fp, _ip, C.c_char_p, C.c_char_p, C.c_int32, _ip]
         L.aln_ctx_set_hint.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         L.aln_ctx_get_hint.argtypes = [C.c_void_p, C.c_char_p, _lp]
         L.aln_deal_units.argtypes = [_lp, C.c_int64, C.c_int32, _ip, _ip]
@@ -182,6 +185,7 @@ class SeqPool:
 class Context:
     def __init__(self, device=0, stream=None):
         self.h = C.c_void_p()
+        self.device = device
         _check(lib().aln_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self.h)))
 
     def synchronize(self):
@@ -379,6 +383,12 @@ class Batch:
     def kernel_name(self):
         return lib().aln_batch_dp_kernel_name(self.h).decode()
 
+    def last_exact_stats(self):
+        """hint exact_debug: far chunks (tested, skipped) of the deletion and the insertion scans of the last tiled exact build"""
+        out = (C.c_uint64 * 4)()
+        _check(lib().aln_batch_last_exact_stats(self.h, out), self.ctx.h)
+        return [int(x) for x in out]
+
     def last_dp_ms(self):
         ms = C.c_float(0)
         _check(lib().aln_batch_last_dp_ms(self.h, C.byref(ms)), self.ctx.h)
@@ -506,18 +516,33 @@ class Batch:
         _check(lib().aln_batch_optimal_collect(self.h, _f(scores), _i(cnt), _i(status)), self.ctx.h)
         return scores, cnt, status
 
+    def _string_buffers(self):
+        stride = max(sum(self.dims(p)) for p in range(self.n)) + 2 if self.n else 4
+        if not hasattr(self, "_tl") or len(self._tl) < self.n * stride:
+            self._tl = C.create_string_buffer(max(self.n * stride, 1))
+            self._ql = C.create_string_buffer(max(self.n * stride, 1))
+        return stride
+
+    def optimal_strings_enqueue(self):
+        """Launch find_max + traceback + the string kernel and the copy of the lines into a pinned slot; returns at once (two slots)."""
+        _check(lib().aln_batch_optimal_strings_enqueue(self.h, self._string_buffers()), self.ctx.h)
+
+    def optimal_strings_collect(self, decode=True):
+        """Wait for the oldest enqueued slot -> like optimal_strings."""
+        return self._strings(lib().aln_batch_optimal_strings_collect, decode)
+
     def optimal_strings(self, decode=True):
         """aln_batch_optimal_strings -> scores[n], identity[n], status[n], template lines, query lines (lists of str, or the
         raw buffers + lengths when decode is False)."""
+        return self._strings(lib().aln_batch_optimal_strings, decode)
+
+    def _strings(self, fn, decode):
         scores = np.empty(self.n, dtype=np.float32)
         ident = np.zeros(self.n, dtype=np.float32)
         status = np.zeros(self.n, dtype=np.int32)
         lengths = np.zeros(self.n, dtype=np.int32)
-        stride = max(sum(self.dims(p)) for p in range(self.n)) + 2 if self.n else 4
-        if not hasattr(self, "_tl") or len(self._tl) < self.n * stride:
-            self._tl = C.create_string_buffer(self.n * stride)
-            self._ql = C.create_string_buffer(self.n * stride)
-        rc = lib().aln_batch_optimal_strings(self.h, _f(scores), _f(ident), _i(status), self._tl, self._ql, stride, _i(lengths))
+        stride = self._string_buffers()
+        rc = fn(self.h, _f(scores), _f(ident), _i(status), self._tl, self._ql, stride, _i(lengths))
         if rc != 0 and rc != E_STARTPAIR:
             _check(rc, self.ctx.h)
         if not decode:

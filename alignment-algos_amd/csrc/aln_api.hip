@@ -92,6 +92,7 @@ int aln_ctx_create(int device_id, void* stream, aln_ctx** out) {
 void aln_ctx_destroy(aln_ctx* ctx) {
   if (!ctx) return;
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   delete ctx;
 }
 
@@ -174,10 +175,10 @@ void aln_batch_destroy(aln_batch* b) {
   hipFree(b->d_pairs); hipFree(b->d_qcodes); hipFree(b->d_tcodes); hipFree(b->d_H); hipFree(b->d_P); hipFree(b->d_S);
   hipFree(b->d_res); hipFree(b->d_table32); hipFree(b->d_tablef); hipFree(b->d_tgi); hipFree(b->d_tge);
   hipFree(b->d_path); hipFree(b->d_bounds); hipFree(b->d_xscratch); hipFree(b->d_tagq); hipFree(b->d_tagstate); hipFree(b->d_deltabR); hipFree(b->d_pair_deloff);
-  if (b->h_path_pin) hipHostFree(b->h_path_pin);
+  aln::free_string_buffers(b);
   if (b->h_stage_pin) hipHostFree(b->h_stage_pin);
   for (auto& sc : b->enum_scratch) hipFree(sc.p);
-  if (b->h_res_pin) hipHostFree(b->h_res_pin); hipFree(b->d_tcn); hipFree(b->d_deltab); hipFree(b->d_deltab_off); hipFree(b->d_instab);
+  hipFree(b->d_tcn); hipFree(b->d_deltab); hipFree(b->d_deltab_off); hipFree(b->d_instab);
   for (int k = 0; k < 2; ++k) { if (b->h_slot[k]) hipHostFree(b->h_slot[k]); if (b->slot_ev[k]) hipEventDestroy(b->slot_ev[k]); }
   for (int k = 0; k < aln_batch::kEvRing; ++k) { if (b->ring0[k]) hipEventDestroy(b->ring0[k]); if (b->ring1[k]) hipEventDestroy(b->ring1[k]); }
   delete b;
@@ -240,13 +241,28 @@ int upload_submatrix(aln_batch* b, const aln_submatrix* sub) {
   uint8_t* tc = qc + nq;
   float* tf = reinterpret_cast<float*>(b->h_stage_pin + ((nq + nt + 15) & ~(size_t)15));
   int32_t* ti = reinterpret_cast<int32_t*>(tf + 1024);
+  // residue -> alphabet index, branch-free inside (an unknown residue is found by OR-ing the lookups), a few host threads for the
+  // megabytes of a big batch: encoding is on the end-to-end path of every new batch
+  uint8_t lut[256];
+  for (int i = 0; i < 256; ++i) lut[i] = idx[i] < 0 ? (uint8_t)0x80 : (uint8_t)idx[i];
+  lut[(unsigned char)'^'] = (uint8_t)kCodeHead; lut[(unsigned char)'$'] = (uint8_t)kCodeTail;
+  auto enc_range = [&lut](const char* src, uint8_t* dst, size_t n) -> int {
+    unsigned bad = 0;
+    for (size_t k = 0; k < n; ++k) { const uint8_t c = lut[(unsigned char)src[k]]; dst[k] = c; bad |= c; }
+    return (bad & 0x80u) ? ALN_E_RESIDUE : ALN_OK;
+  };
   auto enc = [&](const std::string& res, uint8_t* codes) -> int {
-    for (size_t k = 0; k < res.size(); ++k) {
-      const unsigned char ch = (unsigned char)res[k];
-      const int c = (ch == '^') ? kCodeHead : (ch == '$') ? kCodeTail : idx[ch];
-      if (c < 0) return ALN_E_RESIDUE;
-      codes[k] = (uint8_t)c;
+    const size_t n = res.size();
+    const int n_thr = (int)std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), 4, n >> 19}));
+    if (n_thr == 1) return enc_range(res.data(), codes, n);
+    std::vector<int> rcs(n_thr, ALN_OK);
+    std::vector<std::thread> th;
+    for (int k = 0; k < n_thr; ++k) {
+      const size_t lo = n * k / n_thr, hi = n * (k + 1) / n_thr;
+      th.emplace_back([&, k, lo, hi]() { rcs[k] = enc_range(res.data() + lo, codes + lo, hi - lo); });
     }
+    for (auto& x : th) x.join();
+    for (int r : rcs) if (r) return r;
     return ALN_OK;
   };
   int rc = enc(b->q_res, qc);
@@ -306,6 +322,9 @@ int upload_tgaps(aln_batch* b, const aln_gap* gap) {
   if (!b->d_tge) { int rc = dalloc(ctx, &b->d_tge, (size_t)std::max<int64_t>(b->t_total, 1)); if (rc) return rc; }
   if (gap->model != ALN_GAP_TABLES) {             // per-position coefficient arrays (the table model has none)
     if (!gap->t_gap_init || !gap->t_gap_extn) return ALN_E_ARG;
+    bool nonneg = true;                           // gaps that grow with the distance: what the exact kernel's chunk skipping needs
+    for (int64_t k = 0; k < b->t_total; ++k) nonneg = nonneg && (gap->t_gap_extn[k] >= 0.f);
+    b->gap_ext_nonneg = nonneg;
     ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_tgi, gap->t_gap_init, b->t_total * 4, hipMemcpyHostToDevice, ctx->stream));
     ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_tge, gap->t_gap_extn, b->t_total * 4, hipMemcpyHostToDevice, ctx->stream));
   }
@@ -413,6 +432,7 @@ static int prepare_dp(aln_batch* b, const aln_sim* sim, const aln_gap* gap, int3
   b->gapdev.free_ins = (gap->align_type == ALN_LOCAL || gap->align_type == ALN_SEMI_LOCAL || gap->align_type == ALN_GLOBAL_LOCAL);
   int rc;
   bool integral = false;
+  b->gap_ext_nonneg = gap->gap_extn >= 0.f;
   if (gap->model != ALN_GAP_AFFINE_CONST) { rc = upload_tgaps(b, gap); if (rc) return rc; }
   if (sim->kind == ALN_SIM_SUBMATRIX) { rc = upload_submatrix(b, &sim->sub); if (rc) return rc; }
   else if (sim->kind == ALN_SIM_MATRIX) { rc = upload_simplanes(b, sim, &integral); if (rc) return rc; }
@@ -452,6 +472,7 @@ int aln_batch_set_gap(aln_batch* b, const aln_gap* gap) {
   if (gap->model != ALN_GAP_AFFINE_CONST && gap->model != ALN_GAP_AFFINE_TPOS_MIN && gap->model != ALN_GAP_DEL_TABLE_INS_TPOS && gap->model != ALN_GAP_TABLES) return ALN_E_ARG;
   { const int rc = check_gap_arrays(gap); if (rc) return rc; }     // a bad description leaves the batch as it was
   ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));           // nothing may still read the tables that are replaced
+  b->gap_ext_nonneg = gap->gap_extn >= 0.f;
   if (gap->model != ALN_GAP_AFFINE_CONST) {
     const int rc = upload_tgaps(b, gap);
     if (rc) {                       // a device error half way: resident tables may be gone — the batch needs a full aln_batch_dp again
@@ -500,6 +521,14 @@ int aln_batch_dp_sub(aln_batch* b, const aln_sim* sim, const aln_gap* gap, int32
   aln_ctx* ctx = b->ctx;
   ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_pairs, b->h_pairs.data(), sizeof(PairDesc) * b->n_pairs, hipMemcpyHostToDevice, ctx->stream));
   return run_dp(b, false);
+}
+
+// hint exact_debug: far chunks of the last tiled exact build — [0] tested, [1] skipped (far-left deletions), [2] tested, [3] skipped
+// (far insertions); the nearest chunk of every scan is always scanned and never tested
+int aln_batch_last_exact_stats(const aln_batch* b, uint64_t* out4) {
+  if (!b || !out4) return ALN_E_ARG;
+  for (int k = 0; k < 4; ++k) out4[k] = b->exact_stats[k];
+  return ALN_OK;
 }
 
 int aln_batch_last_dp_ms(aln_batch* b, float* ms) {
@@ -686,81 +715,7 @@ int aln_batch_optimal_subali(aln_batch* b, float* scores, int32_t* n, int32_t* p
   return fetch_paths(b, scores, n, pairs, pair_stride, status, true, true);
 }
 
-// Optimal + assignIdentity + SequenceGaps for every pair of the batch: the strings a driver prints for
-// `AlignmentSet alignments(dpm, optimal); alignments.assignIdentity(); cout << FastaOut(len) << alignments`
-// (aa_ali.cpp:83-92, fastaio.h:51-76, gstrings.h:84-164).  Device: find_max + traceback; then the pair lists come to the host
-// and the gapped lines are built there (host_strings.cpp), pair after pair.
-int aln_batch_optimal_strings(aln_batch* b, float* scores, float* identity, int32_t* status, char* tlines, char* qlines,
-                              int32_t stride, int32_t* lengths) {
-  if (!b || !tlines || !qlines || stride < 1) return ALN_E_ARG;
-  if (!b->have_dp || b->have_sub) return ALN_E_STATE;
-  if (b->n_pairs == 0) return ALN_OK;
-  aln_ctx* ctx = b->ctx;
-  int rc = launch_traceback(b, false);
-  if (rc) return rc;
-  const int n = b->n_pairs;
-  // results and pair lists come through pinned buffers the batch keeps (a pageable 16 MB destination costs more than the copy)
-  const size_t path_words = (size_t)n * b->path_stride * 2;
-  if (!b->h_path_pin) {
-    ALN_HIP_CHECK(ctx, hipHostMalloc((void**)&b->h_path_pin, path_words * 4));
-    ALN_HIP_CHECK(ctx, hipHostMalloc((void**)&b->h_res_pin, sizeof(PairResult) * n));
-  }
-  ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->h_res_pin, b->d_res, sizeof(PairResult) * n, hipMemcpyDeviceToHost, ctx->stream));
-  ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->h_path_pin, b->d_path, path_words * 4, hipMemcpyDeviceToHost, ctx->stream));
-  ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  const PairResult* r = b->h_res_pin;
-  const bool corner_score = !b->islocal, flip = b->direction == ALN_FWD;
-  // the strings of different pairs are independent: a few host threads share the pairs
-  const int n_thr = std::max(1, std::min({(int)std::thread::hardware_concurrency(), 8, n / 64 + 1}));
-  std::vector<int> worst_of(n_thr, ALN_OK);
-  auto work = [&](int tid) {
-    std::vector<int32_t> pl;
-    for (int p = tid; p < n; p += n_thr) {
-      const PairDesc& d = b->h_pairs[p];
-      const char* q = b->q_res.data() + d.q_off;
-      const char* t = b->t_res.data() + d.t_off;
-      const int cnt = r[p].n_path;
-      const int32_t* src = b->h_path_pin + (size_t)p * b->path_stride * 2;
-      pl.resize((size_t)std::max(cnt, 1) * 2);
-      for (int k = 0; k < cnt; ++k) {                      // forward builds: device order is end -> start
-        const int sk = flip ? (cnt - 1 - k) : k;
-        pl[2 * k] = src[2 * sk]; pl[2 * k + 1] = src[2 * sk + 1];
-      }
-      char* tl = tlines + (size_t)p * stride;
-      char* ql = qlines + (size_t)p * stride;
-      tl[0] = ql[0] = 0;
-      const float sc = corner_score ? r[p].corner : r[p].best;
-      if (scores) scores[p] = sc;
-      if (status) status[p] = r[p].status;
-      if (lengths) lengths[p] = 0;
-      if (identity) identity[p] = 0.f;
-      int& worst = worst_of[tid];
-      if (r[p].status != 0) { if (worst == ALN_OK) worst = r[p].status; continue; }
-      aln_alignment a = {};
-      a.score = sc; a.n_pairs = cnt; a.pair_off = 0;
-      if (identity) identity[p] = aln_identity(q, d.Q, t, d.T, pl.data(), cnt);
-      // SequenceGaps needs a list that ends at the tail pair and never repeats a pair (Optimal_Rev's local lists can do both)
-      bool printable = cnt > 0 && pl[2 * (cnt - 1)] == d.Q - 1 && pl[2 * (cnt - 1) + 1] == d.T - 1;
-      for (int k = 1; k < cnt && printable; ++k) if (pl[2 * k] == pl[2 * k - 2] && pl[2 * k + 1] == pl[2 * k - 1]) printable = false;
-      if (!printable) continue;
-      const int len = aln_gapped_length(d.T, &a, 1, pl.data());
-      if (len >= stride) { worst = ALN_E_OVERFLOW; continue; }
-      const int rs = aln_gapped_strings(q, d.Q, t, d.T, &a, 1, pl.data(), tl, ql, stride);
-      if (rs != ALN_OK) { if (worst == ALN_OK) worst = rs; continue; }
-      if (lengths) lengths[p] = len;
-    }
-  };
-  if (n_thr == 1) work(0);
-  else {
-    std::vector<std::thread> th;
-    for (int k = 0; k < n_thr; ++k) th.emplace_back(work, k);
-    for (auto& x : th) x.join();
-  }
-  int worst = ALN_OK;
-  for (int w : worst_of) { if (w == ALN_E_OVERFLOW) worst = w; else if (w != ALN_OK && worst == ALN_OK) worst = w; }
-  return worst;
-}
-
+// aln_batch_optimal_strings (+ _enqueue / _collect) live in gapped_strings.hip
 // aln_batch_enumerate lives in enumerate.hip
 
 }  // extern "C"

@@ -34,7 +34,10 @@ const HintDef kDefs[] = {
     {"exact_tiles", "ALN_EXACT_NO_TILES", true, &aln_hints::exact_tiles},
     {"exact_literal", "ALN_EXACT_LITERAL", false, &aln_hints::exact_literal},
     {"exact_alt_prio", "ALN_EXACT_ALT_PRIO", false, &aln_hints::exact_alt_prio},
+    {"exact_prune", "ALN_EXACT_PRUNE", false, &aln_hints::exact_prune},
+    {"exact_debug", "ALN_EXACT_DEBUG", false, &aln_hints::exact_debug},
     {"score_packed", "ALN_SCORE_NO_PACKED", true, &aln_hints::score_packed},
+    {"enum_heavy_first", "ALN_ENUM_HEAVY_FIRST", false, &aln_hints::enum_heavy_first},
     {"enum_pool_retries", "ALN_ENUM_POOL_RETRIES", false, &aln_hints::enum_pool_retries},
     {"enum_waves", "ALN_ENUM_WAVES", false, &aln_hints::enum_waves},
     {"enum_debug", "ALN_ENUM_DEBUG", false, &aln_hints::enum_debug},

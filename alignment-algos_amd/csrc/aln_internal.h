@@ -75,12 +75,15 @@ struct aln_hints {
   int exact_tiles = 1;       // 0: dp_exact_blocked instead of dp_exact_tiled where both apply
   int exact_literal = 0;     // 1: the literal O(n^3) kernel everywhere
   int exact_alt_prio = 1;    // tiled exact kernel: priority rotation over the 4 resident waves
+  int exact_prune = 1;       // tiled exact kernel: skip far chunks that provably cannot matter (bit-exact; dp_exact_blocked.hip)
+  int exact_debug = 0;       // 1: the tiled kernel counts tested / skipped far chunks (aln_batch_last_exact_stats)
   int score_packed = 1;      // 0: one query per wave in aln_score_all_vs_all
   int plane_row_align = 8;   // cells a plane row is padded to when a batch is created (8, 16, 32 or 64)
   int64_t enum_node_cap = 0; // trie nodes of aln_batch_enumerate (0 = default)
   int enum_keep_pools = 1;   // 1: aln_batch_enumerate_all keeps its device pools with the batch (freed with it); 0: frees them when it returns
   int enum_debug = 0;        // 1: aln_batch_enumerate_all reports every group of pairs it searches on stderr
   int enum_waves = 0;        // cw / ucw search: waves per pair (enumerate_par.hip); 0 = by the number of pairs, 1 = the one-wave kernel
+  int enum_heavy_first = 1;  // aln_batch_enumerate_all: launch the pairs in the order of what the batch's previous search used, heaviest first
   int enum_pool_retries = 2; // aln_batch_enumerate_all: times a pair whose pools overflowed is searched again with 4 x the capacity
 };
 
@@ -90,6 +93,7 @@ struct aln_ctx {
   int device;
   hipStream_t stream;
   bool own_stream;
+  hipStream_t copy_stream = nullptr;   // device -> host copies that must not hold up the launch stream (created on first use)
   std::string last_error;
   aln_hints hints;
 };
@@ -132,6 +136,8 @@ struct aln_batch {
   aln_gap gap;                                 // host copy (pointers not retained beyond dp call)
   aln::GapDev gapdev;
   bool islocal;
+  bool gap_ext_nonneg = true;                  // every gap extension coefficient of the last description is >= 0 (gaps grow with distance)
+  unsigned long long exact_stats[4] = {0, 0, 0, 0};   // hint exact_debug: far chunks tested / skipped, deletions then insertions
   bool simplane_integral = false;              // ALN_SIM_MATRIX planes of the last dp were all small integers (kept for reevaluate)
   int32_t ptr_mode;                            // encoding of the P plane words (aln_device.h decode_ptr)
   int32_t h_mode;                              // score plane element type: 0 fp32, 1 uint16 (aln_device.h load_score)
@@ -151,7 +157,13 @@ struct aln_batch {
   hipEvent_t slot_ev[2] = {nullptr, nullptr};
   bool slot_local[2] = {false, false};
   int slot_head = 0, slot_count = 0;
-  int32_t* h_path_pin = nullptr; aln::PairResult* h_res_pin = nullptr;   // pinned readout buffers of aln_batch_optimal_strings
+  // aln_batch_optimal_strings_enqueue / _collect (gapped_strings.hip): residue characters on the device, two device + two pinned slots
+  char* d_qchars = nullptr; char* d_tchars = nullptr;
+  char* d_str_lines[2] = {nullptr, nullptr}; char* h_str_lines[2] = {nullptr, nullptr};
+  void* d_str_out[2] = {nullptr, nullptr}; void* h_str_out[2] = {nullptr, nullptr};
+  hipEvent_t str_ev[2] = {nullptr, nullptr}, str_kernel_ev[2] = {nullptr, nullptr};
+  int32_t str_stride = 0;
+  int str_head = 0, str_count = 0;
   std::vector<int32_t> h_bounds;
   // retained similarity description for reevaluate()
   std::vector<float> h_table; int32_t alpha_n; std::string alphabet;
@@ -185,6 +197,8 @@ int launch_dp_affine_solo(aln_batch* b);
 int launch_dp_corner(aln_batch* b);
 // traceback.hip
 int launch_traceback(aln_batch* b, bool subali);
+// gapped_strings.hip
+void free_string_buffers(aln_batch* b);
 // dp_exact.hip
 int launch_dp_exact(aln_batch* b);
 // dp_exact_blocked.hip

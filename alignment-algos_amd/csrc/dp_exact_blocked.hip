@@ -499,7 +499,32 @@ __device__ __forceinline__ void sload_rows2(f2v (&dst)[NR], const float* p) {
     sload_rows2<R + 1, NR, PTC>(dst, p);
   }
 }
+typedef float f16v __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f16v sload16(const float* p) {
+  f16v v;
+  // load and wait in ONE statement: between a lone s_load and a later s_waitcnt the compiler may move or spill the destination
+  // registers (this kernel spills SGPRs), which would read them before the data arrives
+  asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
 __device__ __forceinline__ void swait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// ---- skipping whole chunks of far candidates (bit-exact) ------------------------------------------------------------------------
+// A far scan keeps, per cell, (m, e, c) = the best d = D_k - g_k, the chunk c that attains it first and the best d of the chunks
+// before c.  Chunks are visited NEAREST FIRST.  A chunk K may be left out when, for every cell the wave serves,
+//        ub(K) + margin < m            ub(K) = fl(max_{k in K} D_k - g_lb(K)),  g_lb = the smallest gap any k in K can have
+// (gaps grow with the distance as long as the extension coefficients are >= 0; rounding is monotone, so ub >= every d of K):
+//  * no d of K reaches m, so neither m nor "first chunk attaining m" changes;
+//  * `e` would change only if K lies before c — and e is used for one thing, the test fl(e + S) == fl(m + S) that sends a
+//    cell won by a gap to the literal re-walk from the start.  fl(x + S) == fl(y + S) with x < y needs y - x <= ulp(fl(y + S))
+//    <= 2^-23 (|y| + |S|); the margin 2^-21 (|m| + max|S| + 1) (minus what the two roundings of its own computation can lose)
+//    excludes it.  So every cell's score and pointer come out exactly as if K had been scanned.
+// The maxima come from what the kernel already produced: per finished row the maximum of every 32-column chunk (deletion
+// scans; 16 rows of a chunk = one s_load_dwordx16), per column the maximum of every 16-row block (insertion scans).
+// Measured on config 3 (2000 x 2000 profile pairs, global): 88 % of the far-left deletion chunks and 86 % of the far insertion
+// chunks are skipped (tools/c3_prune_estimate.py replays the rule on the host).
+constexpr float kPruneEps = 4.76837158203125e-07f;     // 2^-21
+__device__ __forceinline__ float prune_thr(float m, float ceps) { return __builtin_fmaf(__builtin_fabsf(m), -kPruneEps, m) - ceps; }
 __device__ __forceinline__ float vmin_sv(float s, float v) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "s"(s), "v"(v)); return r; }
 
 constexpr int kTW = 256;       // tile width = threads
@@ -519,9 +544,12 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
                                                                  float* __restrict__ Hbase, uint32_t* __restrict__ Pbase,
                                                                  const float* __restrict__ Sbase, PairResult* __restrict__ res, int rev,
                                                                  float* __restrict__ scratch_base, int alt_prio,
-                                                                 const float* __restrict__ delF_base, const int64_t* __restrict__ delF_off) {
+                                                                 const float* __restrict__ delF_base, const int64_t* __restrict__ delF_off,
+                                                                 int prune, int q_blocks, const float* __restrict__ smax_arr, float smax_const,
+                                                                 unsigned long long* __restrict__ dbg) {
   constexpr bool TPOS = GM == 1;
   constexpr bool TAB = GM == 2;
+  __shared__ float2 cminl[PT / 32 + 1];                 // per 32-column chunk: the smallest (tgi, tge) in it (frame order)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float2* tg = reinterpret_cast<float2*>(lds);          // (tgi, tge) in frame order, PT entries
   float* rowloc0 = lds + 2 * PT;                         // rows a-1 / a of the current tile, index k - kbase
@@ -555,7 +583,7 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
   auto del_at = [&](int k, int b) -> float { return delF[(size_t)(k < TT ? k : TT - 1) * TT + b]; };   // k clamped: masked candidates only
   // per-workgroup scratch: far-insertion and far-left-deletion results [2][3][kBR][PT] (own words only, read back through L2),
   // finished rows in frame order [kTRing][PT], (tgi, tge) [2][PT]
-  float* scr_m = scratch_base + (size_t)blockIdx.x * (size_t)(6 * kBR + kTRing + 2) * PT;
+  float* scr_m = scratch_base + (size_t)blockIdx.x * (size_t)(6 * kBR + kTRing + 3 + q_blocks) * PT;
   float* scr_e = scr_m + kBR * PT;
   int* scr_c = reinterpret_cast<int*>(scr_e + kBR * PT);
   float* fdm = scr_m + 3 * kBR * PT;
@@ -564,6 +592,12 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
   float* rowsF = scr_m + 6 * kBR * PT;
   float* tgiF = rowsF + kTRing * PT;
   float* tgeF = tgiF + PT;
+  float* delmaxF = tgeF + PT;                            // [PT/32 chunks][kTRing row slots]: chunk maxima of finished rows
+  float* insmaxF = delmaxF + PT;                         // [q_blocks][PT]: column maxima of finished 16-row blocks
+  const float ceps = ((smax_arr ? smax_arr[blockIdx.x] : smax_const) + 1.0f) * kPruneEps;
+  const bool prune_del = (prune & 1) && !TAB;            // a tabulated deletion has no monotone lower bound
+  const bool prune_ins = (prune & 2) != 0;
+  unsigned n_tested_d = 0, n_skip_d = 0, n_tested_i = 0, n_skip_i = 0;
 
   float lmax = 0.f; uint32_t lpos = 0xFFFFFFFFu;
   const uint32_t origin = pack_ptr(f.rq(0), f.rt(0));
@@ -578,6 +612,13 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
     }
     for (int x = tid; x < 2 * kTLoc; x += kTW) rowloc0[x] = ninf;
     __threadfence_block();
+    __syncthreads();
+    for (int c = tid; c < PT / 32; c += kTW) {
+      float2 mn = tg[32 * c];
+#pragma unroll 8
+      for (int u = 1; u < 32; ++u) { const float2 v = tg[32 * c + u]; mn.x = fminr(mn.x, v.x); mn.y = fminr(mn.y, v.y); }
+      cminl[c] = mn;
+    }
     __syncthreads();
     const int ntiles = (nT - 1 + kTW - 1) / kTW;
 
@@ -600,30 +641,41 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
         const int bc = kbase + 1 + tid;                // this thread's column
         const bool bv = bc <= nT - 1;
         const bool wave_on = kbase + 1 + 64 * wave <= nT - 1;
+        float colmax = ninf;                           // this column's maximum over the rows of the block (tile epilogue)
         // ============ far insertions of rows a0 .. a0+15 for column bc: candidates k = 1 .. a0-2 =====================
+        // Source rows in chunks of 16 that coincide with the row blocks (rows 16j+1 .. 16j+16), nearest chunk first; (m, e, c)
+        // as a left-to-right walk would leave them: c = the LOWEST chunk that attains m (a tie moves it down: >=), e = the best
+        // of the chunks below c (reset whenever c moves).  Chunks other than the nearest are tested against the column maximum
+        // of their row block and skipped when they cannot matter ("skipping whole chunks" above).
         if (a0 >= 3 && wave_on) {
           const int b = (bc < 2 || !bv) ? 2 : bc;
           float gi = gi_c, ge = ge_c, cn = 0.f;
           if (TPOS) { const float2 t0 = tg[b - 1], t1 = tg[b]; gi = fminr(t0.x, t1.x); ge = fminr(t0.y, t1.y); }
           if (TAB) { const int lo = rev ? b : b - 1; const float2 t = tg[lo]; gi = t.x; ge = t.y; cn = tcnl[lo]; }   // the smaller real position
           const size_t colb = (size_t)f.rt(b - 1);
+          const float* cmaxcol = insmaxF + (b - 1);
+          const bool lane_live = bv && bc >= 2;
+          const int jtop = (a0 - 3) >> 4;              // the chunk that holds row a0-2
           constexpr int HW = kBR / 2;                  // two 8-row windows: half the registers of one 16-row window
 #pragma unroll 1
           for (int h = 0; h < 2; ++h) {
             float W[HW], cm[HW], m[HW], ee[HW]; int cc[HW];
-            float fn = (float)(a0 + HW * h - 2);       // n of (row a0 + 8h, k = 0)
 #pragma unroll
-            for (int i = 0; i < HW; ++i) {
-              W[i] = gi + ge * (fn + (float)i);
-              if (TAB) W[i] = W[i] + cn;                    // gn2_eval.h: gp = gi + ge * (di - 2); gp = gp + cn
-              cm[i] = ninf; m[i] = ninf; ee[i] = ninf; cc[i] = 0;
-            }
-            for (int kc = 0; kc <= a0 - 2; kc += kBR) {
+            for (int i = 0; i < HW; ++i) { m[i] = ninf; ee[i] = ninf; cc[i] = 0; }
+            auto scan_chunk = [&](int j) {                 // rows 16j+1 .. 16j+16 (those <= a0-2) against the window's 8 target rows
+              const int kc = 1 + 16 * j;
+              float fn = (float)(a0 + HW * h - 2 - kc);   // n of (row a0 + 8h, k = kc)
+#pragma unroll
+              for (int i = 0; i < HW; ++i) {
+                W[i] = gi + ge * (fn + (float)i);
+                if (TAB) W[i] = W[i] + cn;                    // gn2_eval.h: gp = gi + ge * (di - 2); gp = gp + cn
+                cm[i] = ninf;
+              }
               float x[kBR];
 #pragma unroll
               for (int u = 0; u < kBR; ++u) {
                 const int k = kc + u;
-                x[u] = (k >= 1 && k <= a0 - 2) ? aload(&H[(size_t)f.rq(k) * ld + colb]) : ninf;
+                x[u] = (k <= a0 - 2) ? aload(&H[(size_t)f.rq(k) * ld + colb]) : ninf;
               }
 #pragma unroll
               for (int u = 0; u < kBR; ++u) {
@@ -636,11 +688,48 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
               }
 #pragma unroll
               for (int r = 0; r < HW; ++r) {
-                const bool up = cm[r] > m[r];
-                ee[r] = up ? m[r] : ee[r];
+                const bool up = cm[r] >= m[r];
+                ee[r] = up ? ninf : vmaxf(ee[r], cm[r]);
                 cc[r] = up ? kc : cc[r];
                 m[r] = up ? cm[r] : m[r];
-                cm[r] = ninf;
+              }
+            };
+            scan_chunk(jtop);                              // the nearest chunk: always
+            // the others in groups of 8, nearest group first: the group's 8 column maxima are loaded together (one memory
+            // latency per group instead of one per chunk), every chunk is tested against the state BEFORE the group (m only
+            // grows, so a chunk that may be skipped now may be skipped later), the chunks that fail are scanned nearest first
+#pragma unroll 1
+            for (int jg = jtop - 1; jg >= 0; jg -= 8) {
+              const int ng = jg + 1 < 8 ? jg + 1 : 8;
+              unsigned todo = (1u << ng) - 1u;             // bit t = chunk jg - t
+              if (prune_ins) {
+                float cmxv[8], thr[HW];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) cmxv[t] = (t < ng) ? aload(cmaxcol + (size_t)(jg - t) * PT) : ninf;
+#pragma unroll
+                for (int i = 0; i < HW; ++i) thr[i] = (a0 + HW * h + i > a_end) ? __builtin_inff() : prune_thr(m[i], ceps);
+                todo = 0u;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                  if (t < ng) {
+                    const float fn0 = (float)(a0 + HW * h - 2 - (1 + 16 * (jg - t) + 15));   // n of (first window row, nearest row of the chunk)
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < HW; ++i) {
+                      float gl = gi + ge * (fn0 + (float)i);
+                      if (TAB) gl = gl + cn;
+                      ok = ok && (cmxv[t] - gl < thr[i]);
+                    }
+                    if (__ballot(ok || !lane_live) != ~0ull) todo |= 1u << t;
+                  }
+                }
+                n_tested_i += (unsigned)ng;
+                n_skip_i += (unsigned)(ng - __builtin_popcount(todo));
+              }
+              while (todo) {
+                const int t = __builtin_ctz(todo);
+                todo &= todo - 1u;
+                scan_chunk(jg - t);
               }
             }
             if (bv && bc >= 2) {
@@ -652,20 +741,44 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
           }
         }
         // ============ far-left deletions: sources k = 1 .. kbase-1 of rows a0-1 .. a0+14, shared gap values ===========
+        // 32-column chunks, nearest first, same (m, e, c) convention and skip rule as the far insertions; the 16 rows' maxima of
+        // a chunk are one s_load_dwordx16.
         if (cb >= 1 && a_end >= 2 && wave_on) {
           __builtin_amdgcn_s_dcache_inv();             // the source rows were written through the vector path
           const int b = bv ? bc : kbase + 1;
           float gib = 0.f, geb = 0.f;
           if (TPOS) { const float2 t = tg[b]; gib = t.x; geb = t.y; }
-          float fd = (float)(b - 2);
           float cm[kBR], m[kBR], ee[kBR]; int cc[kBR];
 #pragma unroll
-          for (int r = 0; r < kBR; ++r) { cm[r] = ninf; m[r] = ninf; ee[r] = ninf; cc[r] = 0; }
+          for (int r = 0; r < kBR; ++r) { m[r] = ninf; ee[r] = ninf; cc[r] = 0; }
           // source row of target row a0+r is a0+r-1: ring slots (a0-1) & 31 + r — consecutive, because a0-1 is a multiple of 16
-          const float* sbase = rowsF + (size_t)((a0 - 1) & (kTRing - 1)) * PT;
+          const int slot0 = (a0 - 1) & (kTRing - 1);
+          const float* sbase = rowsF + (size_t)slot0 * PT;
+          const float* mbase = delmaxF + slot0;
+          const int r_lo = (a0 == 1) ? 1 : 0, r_hi = a_end - a0;      // target rows whose far-left state is used
+          const int ctop = kbase / kBC - 1;
           // 4 source columns x 16 rows per trip: 18 scalar loads, one wait, 148 VALU instructions.  (Double-buffering the
           // SGPRs was tried: under the kernel's SGPR pressure the compiler copies the in-flight registers and waits early.)
-          for (int kc = 0; kc < kbase; kc += kBC) {
+#pragma unroll 1
+          for (int c = ctop; c >= 0; --c) {
+            const int kc = c * kBC;
+            if (prune_del && c != ctop) {
+              const f16v mx = sload16(mbase + (size_t)c * kTRing);
+              const float2 cmn = cminl[c];
+              const float dist = (float)(b - (kc + kBC - 1) - 2);
+              const float g_lb = (TPOS ? fminr(cmn.x, gib) : gi_c) + (TPOS ? fminr(cmn.y, geb) : ge_c) * dist;
+              bool ok = true;
+#pragma unroll
+              for (int r = 0; r < kBR; ++r) {
+                const float ub = mx[r] - g_lb;
+                ok = ok && ((ub < prune_thr(m[r], ceps)) || r < r_lo || r > r_hi);
+              }
+              ++n_tested_d;
+              if (__ballot(ok || !bv) == ~0ull) { ++n_skip_d; continue; }
+            }
+            float fd = (float)(b - 2 - kc);
+#pragma unroll
+            for (int r = 0; r < kBR; ++r) cm[r] = ninf;
 #pragma unroll 1
             for (int k = kc; k < kc + kBC; k += 4) {
               f4v src[kBR];
@@ -692,11 +805,10 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
             }
 #pragma unroll
             for (int r = 0; r < kBR; ++r) {
-              const bool up = cm[r] > m[r];
-              ee[r] = up ? m[r] : ee[r];
+              const bool up = cm[r] >= m[r];
+              ee[r] = up ? ninf : vmaxf(ee[r], cm[r]);
               cc[r] = up ? kc : cc[r];
               m[r] = up ? cm[r] : m[r];
-              cm[r] = ninf;
             }
           }
 #pragma unroll
@@ -869,6 +981,7 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
               H[(size_t)i * ld + jj] = opt; P[(size_t)i * ld + jj] = optp;
               rowF[bc] = opt;
               curl[1 + tid] = opt;
+              colmax = vmaxf(colmax, opt);
               const uint32_t pos = ((uint32_t)a << 16) | (uint32_t)bc;
               if (opt > lmax || (opt == lmax && pos < lpos)) { lmax = opt; lpos = pos; }   // tiles are not visited in row-major order
             } else {
@@ -881,8 +994,35 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
           __threadfence_block();
           __syncthreads();
         }
+        // ============ tile epilogue: the maxima later far scans test their chunks against ==============================
+        if (prune) {
+          if (bv) insmaxF[(size_t)((a0 - 1) >> 4) * PT + bc] = colmax;          // this column over the rows of the block
+          {
+            // rows a0 .. a_end x this tile's 8 chunks [kbase + 32 j, kbase + 32 j + 31]: 16 threads per row, 2 per chunk
+            const int r = tid >> 4, j = (tid & 15) >> 1, half = tid & 1;
+            const int a = a0 + r;
+            float mxv = ninf;
+            if (a <= a_end) {
+              const float* rowp = rowsF + (size_t)(a & (kTRing - 1)) * PT;
+              const int k0 = kbase + 32 * j + 16 * half;
+              float v[16];
+#pragma unroll
+              for (int u = 0; u < 16; ++u) v[u] = (k0 + u >= 1 && k0 + u <= nT - 1) ? aload(&rowp[k0 + u]) : ninf;
+#pragma unroll
+              for (int u = 0; u < 16; ++u) mxv = vmaxf(mxv, v[u]);
+            }
+            mxv = vmaxf(mxv, __shfl_xor(mxv, 1));
+            if (half == 0 && a <= a_end) delmaxF[(size_t)(kbase / 32 + j) * kTRing + (a & (kTRing - 1))] = mxv;
+          }
+          __threadfence_block();
+          __syncthreads();
+        }
       }
     }
+  }
+  if (dbg && (threadIdx.x & 63) == 0) {
+    atomicAdd(&dbg[0], (unsigned long long)n_tested_d); atomicAdd(&dbg[1], (unsigned long long)n_skip_d);
+    atomicAdd(&dbg[2], (unsigned long long)n_tested_i); atomicAdd(&dbg[3], (unsigned long long)n_skip_i);
   }
   float m = lmax; uint32_t p = lpos;
 #pragma unroll
@@ -931,6 +1071,21 @@ bool dp_exact_blocked_legal(const aln_batch* b) {
   return mx <= 16 * 256 && b->gapdev.model != ALN_GAP_TABLES;   // a plugin's fully tabulated gap functions run in the literal kernel
 }
 
+// max |S| over a pair's resident similarity plane (the rounding margin of the chunk-skipping tests)
+__global__ __launch_bounds__(256) void plane_absmax_kernel(const PairDesc* __restrict__ pairs, const float* __restrict__ Sbase,
+                                                           float* __restrict__ out) {
+  __shared__ float red[4];
+  const PairDesc pd = pairs[blockIdx.x];
+  const float* S = Sbase + pd.plane_off;
+  const size_t n = (size_t)pd.Q * pd.ld;
+  float mx = 0.f;
+  for (size_t k = threadIdx.x; k < n; k += 256) mx = fmaxf(mx, fabsf(S[k]));
+  for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
 // tabR[x][y] = tab[T-1-y][T-1-x]: the deletion table of a template as a REVERSE build's frame sees it
 __global__ void flip_transpose_kernel(const float* __restrict__ tab, float* __restrict__ tabR, int T) {
   __shared__ float tile[16][17];
@@ -952,7 +1107,10 @@ int launch_dp_exact_blocked(aln_batch* b) {
   const bool gn2 = b->gapdev.model == ALN_GAP_DEL_TABLE_INS_TPOS;
   const bool tiled = gn2 || (mx > 2 * kTW && (ctx->hints.exact_tiles || mx > 8 * kTW));   // the slot kernel ends at 8 x 256 columns and knows no tables
   const int ptt = (mx + 1 <= 4 * kTW ? 4 : mx + 1 <= 8 * kTW ? 8 : mx + 1 <= 12 * kTW ? 12 : 16) * kTW + kBPad;          // row pitch of the scratch rows: a compile-time constant of the kernel
-  const size_t need = tiled ? (size_t)(6 * kBR + kTRing + 2) * ptt * (size_t)b->n_pairs : blocked_scratch_floats(ns) * (size_t)b->n_pairs;
+  // tiled kernel: + one row of chunk maxima + one row of column maxima per 16-row block (the skip tests of the far scans) + max|S| per pair
+  const int q_blocks = (b->maxQ + kBR - 1) / kBR + 1;
+  const size_t need = tiled ? (size_t)(6 * kBR + kTRing + 3 + q_blocks) * ptt * (size_t)b->n_pairs + (size_t)b->n_pairs + 64
+                            : blocked_scratch_floats(ns) * (size_t)b->n_pairs;
   if (b->xscratch_floats < need) {
     if (b->d_xscratch) { ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); hipFree(b->d_xscratch); b->d_xscratch = nullptr; b->xscratch_floats = 0; }
     if (hipMalloc((void**)&b->d_xscratch, need * 4) != hipSuccess) { ctx->last_error = "hipMalloc (far-insertion scratch)"; return ALN_E_NOMEM; }
@@ -1002,11 +1160,29 @@ int launch_dp_exact_blocked(aln_batch* b) {
       proto.tcn = b->d_tcn; proto.deltab = b->d_deltab; proto.deltab_off = b->d_deltab_off;
     }
     const int alt_prio = ctx->hints.exact_alt_prio;      // aln_ctx_set_hint "exact_alt_prio"
+    // Skipping far chunks by bounds needs gaps that grow with the distance: extension coefficients >= 0 (checked when they were
+    // uploaded) — and max|S| for the rounding margin: the table's for codes + table, a reduction over the resident plane otherwise.
+    // hint exact_prune: 1 = both far scans, 2 = the far-left deletions only, 3 = the far insertions only (development), 0 = off
+    const int hp = ctx->hints.exact_prune;
+    const int prune = !b->gap_ext_nonneg ? 0 : hp == 1 ? 3 : hp == 2 ? 1 : hp == 3 ? 2 : 0;
+    float* d_smax = nullptr;
+    float smax_const = 0.f;
+    if (sub) { for (float v : b->h_table) smax_const = std::max(smax_const, std::fabs(v)); }
+    else if (prune) {
+      d_smax = b->d_xscratch + (size_t)(6 * kBR + kTRing + 3 + q_blocks) * ptt * (size_t)b->n_pairs;
+      hipLaunchKernelGGL(plane_absmax_kernel, dim3(b->n_pairs), dim3(256), 0, ctx->stream, b->d_pairs, b->d_S, d_smax);
+      ALN_HIP_CHECK(ctx, hipGetLastError());
+    }
+    unsigned long long* d_dbg = nullptr;
+    if (ctx->hints.exact_debug) {
+      d_dbg = reinterpret_cast<unsigned long long*>(b->d_xscratch + ((need - 16) & ~(size_t)1));
+      ALN_HIP_CHECK(ctx, hipMemsetAsync(d_dbg, 0, 32, ctx->stream));
+    }
 #define ALN_TLAUNCH(PTC, GM_, LC)                                                                                                \
     hipLaunchKernelGGL((dp_exact_tiled_kernel<PTC, GM_, LC>), dim3(b->n_pairs), dim3(kTW), lds, ctx->stream, b->d_pairs, proto,    \
                        sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, (tpos || gn2) ? b->d_tgi : nullptr,               \
                        (tpos || gn2) ? b->d_tge : nullptr, b->d_H, b->d_P, sub ? nullptr : b->d_S, b->d_res, rev, b->d_xscratch,   \
-                       alt_prio, delF, b->d_pair_deloff)
+                       alt_prio, delF, b->d_pair_deloff, prune, q_blocks, d_smax, smax_const, d_dbg)
 #define ALN_TLAUNCH_P(PTC)                                                                                                       \
     do { if (gn2) { if (b->islocal) ALN_TLAUNCH(PTC, 2, true); else ALN_TLAUNCH(PTC, 2, false); }                                \
          else if (tpos) { if (b->islocal) ALN_TLAUNCH(PTC, 1, true); else ALN_TLAUNCH(PTC, 1, false); }                          \
@@ -1018,6 +1194,10 @@ int launch_dp_exact_blocked(aln_batch* b) {
 #undef ALN_TLAUNCH_P
 #undef ALN_TLAUNCH
     ALN_HIP_CHECK(ctx, hipGetLastError());
+    if (d_dbg) {                                         // chunks tested / skipped, far-left deletions then far insertions (per wave)
+      ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->exact_stats, d_dbg, 32, hipMemcpyDeviceToHost, ctx->stream));
+      ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     b->kernel_name = std::string("dp_exact_tiled_kernel<") + (gn2 ? "gn2tab," : tpos ? "tpos," : "const,") + (b->islocal ? "local" : "global") +
                      (b->direction == ALN_REV ? ",rev>" : ",fwd>");
     return ALN_OK;

@@ -645,25 +645,29 @@ __global__ __launch_bounds__(64) void enum_unroll_all_kernel(const uint32_t* __r
                                                              const int32_t* __restrict__ sel, int K, const int32_t* __restrict__ pair_list,
                                                              const int32_t* __restrict__ path,
                                                              int path_stride, const PairResult* __restrict__ res,
-                                                             int32_t* __restrict__ out_pairs, int32_t* __restrict__ out_n, int stride) {
-  // blockIdx.y = position of the pair inside its group (pools, sel and outputs are group-local); gp = its index in the batch
+                                                             int32_t* __restrict__ out_pairs, int32_t* __restrict__ out_n, int stride,
+                                                             int out_by_pair) {
+  // blockIdx.y = position of the pair inside its group (pools and sel are group-local); gp = its index in the batch.  The outputs
+  // are group-local too, unless the group is the whole batch (out_by_pair): then they are laid out in batch order, whatever
+  // order the pairs were launched in, and the host takes them with one copy.
   const int p = blockIdx.y, k = blockIdx.x;
   const int gp = pair_list[p];
   const int idx = sel[(size_t)p * K + k];
-  int32_t* o = out_pairs ? out_pairs + ((size_t)p * K + k) * stride * 2 : nullptr;
-  if (idx < 0) { if (threadIdx.x == 0) out_n[(size_t)p * K + k] = 0; return; }
+  const size_t op = out_by_pair ? (size_t)gp : (size_t)p;
+  int32_t* o = out_pairs ? out_pairs + (op * K + k) * stride * 2 : nullptr;
+  if (idx < 0) { if (threadIdx.x == 0) out_n[op * K + k] = 0; return; }
   if (idx == 0) {
     const int n = res[gp].n_path;
     const int32_t* src = path + (size_t)gp * path_stride * 2;
     if (o) for (int i = threadIdx.x; i < n && i < stride; i += 64) { o[2 * i] = src[2 * (n - 1 - i)]; o[2 * i + 1] = src[2 * (n - 1 - i) + 1]; }
-    if (threadIdx.x == 0) out_n[(size_t)p * K + k] = n;
+    if (threadIdx.x == 0) out_n[op * K + k] = n;
     return;
   }
   // a slice per pair (one-wave kernels: n_pools = 0) or the pool workgroup p of enumerate_par.hip used (enum_pool_of)
   const size_t nbase = n_pools ? (size_t)enum_pool_of((uint32_t)p, (uint32_t)n_pools) * node_stride : (size_t)p * node_stride;
   const int n = unroll_alignment(node_pair + nbase, node_next + nbase, node_len ? node_len + nbase : nullptr,
                                  head[(size_t)p * ali_cap + idx], o, stride);
-  if (threadIdx.x == 0) out_n[(size_t)p * K + k] = n;
+  if (threadIdx.x == 0) out_n[op * K + k] = n;
 }
 }  // namespace aln
 
@@ -750,6 +754,12 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   std::vector<PairResult> res(n);
   BTRY(hipMemcpyAsync(res.data(), b->d_res, sizeof(PairResult) * n, hipMemcpyDeviceToHost, ctx->stream));
   BTRY(hipStreamSynchronize(ctx->stream));
+  // what the previous search of this batch used, if there was one: the pairs are launched heaviest first (below)
+  std::vector<int32_t> prior_nodes;
+  if ((int)b->enum_usage.size() == 4 * n && ctx->hints.enum_heavy_first) {
+    prior_nodes.resize(n);
+    for (int p = 0; p < n; ++p) prior_nodes[p] = b->enum_usage[(size_t)p * 4 + 1];
+  }
   b->enum_usage.assign((size_t)n * 4, 0);
   b->enum_search_ms = b->enum_unroll_ms = 0.f;
   if (par_waves(b, noa->kind, n) || noa->kind == ALN_ENUM_KSCW) {   // block maxima of every pair's score plane, once (the pruned scans of enumerate_par.hip / enumerate_ks.hip)
@@ -766,6 +776,12 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   const size_t kPoolBudget = (size_t)48 << 30;                       // bytes of pools of one group
   std::vector<int32_t> todo((size_t)n);
   for (int p = 0; p < n; ++p) todo[p] = p;
+  // Workgroup g of a launch searches pair todo[g], and workgroups start in index order as residency frees up.  A search's length is
+  // unknown beforehand (nothing, or 27 M trie nodes), and the longest pair bounds a launch — unless it starts first.  When this
+  // batch has been searched before (refinement rounds, a sweep over DELTA_RATIO, bench.py's second call), the pairs go in the
+  // order of what they used then, heaviest first; results are stored per pair and do not depend on the order.
+  if (!prior_nodes.empty())
+    std::stable_sort(todo.begin(), todo.end(), [&](int32_t x, int32_t y) { return prior_nodes[x] > prior_nodes[y]; });
   uint32_t node_cap = node_cap_per_pair ? node_cap_per_pair : (1u << 20);
   uint32_t ali_cap = ali_cap_per_pair ? ali_cap_per_pair : 65536u;
   std::vector<int32_t> hout, sel, hlens, hlists, old_of_new;
@@ -932,18 +948,19 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
     hipLaunchKernelGGL(enum_unroll_all_kernel, dim3(K, gn), dim3(64), 0, ctx->stream, a.node_pair, a.node_next,
                        pw ? a.node_len : (const uint8_t*)nullptr, a.head,
                        pw ? (size_t)a.n_chunks * kChunkNodes : (size_t)a.node_cap, pw ? (int)a.n_pools : 0, a.ali_cap,
-                       d_sel, K, d_list, b->d_path, b->path_stride, b->d_res, d_lists, d_lens, pairs ? pair_stride : (1 << 30));
+                       d_sel, K, d_list, b->d_path, b->path_stride, b->d_res, d_lists, d_lens, pairs ? pair_stride : (1 << 30),
+                       gn == n ? 1 : 0);
     BTRY(hipGetLastError());
     BTRY(hipEventRecord(evs[3], ctx->stream));
     hlens.resize(sel.size());
     BTRY(hipMemcpyAsync(hlens.data(), d_lens, sel.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    const bool in_place = pairs && gn == n;             // every pair of the batch, in batch order: one copy
+    const bool in_place = pairs && gn == n;             // every pair of the batch: laid out in batch order by the kernel, one copy
     if (in_place) BTRY(hipMemcpyAsync(pairs, d_lists, sel.size() * (size_t)pair_stride * 8, hipMemcpyDeviceToHost, ctx->stream));
     BTRY(hipStreamSynchronize(ctx->stream));
     for (int g = 0; g < gn; ++g) {
       const int p = ids[g];
       if (deferred[g] == 1) continue;
-      for (int k = 0; k < K; ++k) lengths[(size_t)p * K + k] = hlens[(size_t)g * K + k];
+      for (int k = 0; k < K; ++k) lengths[(size_t)p * K + k] = hlens[(size_t)(gn == n ? p : g) * K + k];
       if (pairs && !in_place)
         BTRY(hipMemcpy(pairs + (size_t)p * K * pair_stride * 2, d_lists + (size_t)g * K * pair_stride * 2, (size_t)K * pair_stride * 8,
                        hipMemcpyDeviceToHost));

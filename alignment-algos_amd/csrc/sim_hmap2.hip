@@ -12,9 +12,9 @@
 //                      registers, the row's profile is broadcast from LDS; expf is the host libm's algorithm
 //                      (glibc flt-32/e_expf.c: 32-entry 2^(i/32) table, degree-3 polynomial in double) so the
 //                      bits match the CPU evaluator;
-//  hmap2_stats_kernel  one wave per pair; 64 coalesced elements per step, then the two fp32 sums are
+//  hmap2_stats_kernel  two waves per pair (one per sum); 64 coalesced elements per step, each fp32 sum is
 //                      accumulated one element at a time in the reference's order (a parallel reduction would
-//                      round differently);
+//                      round differently) by a value that rotates through the lanes;
 //  hmap2_apply_kernel  elementwise (x - avg) / std + shift over the interior.
 #include <algorithm>
 #include <cmath>
@@ -136,16 +136,26 @@ __global__ __launch_bounds__(kSimThreads) void hmap2_sim_kernel(const PairDesc* 
   }
 }
 
-__global__ __launch_bounds__(64) void hmap2_stats_kernel(const PairDesc* __restrict__ pairs, const float* __restrict__ Sbase,
-                                                         float* __restrict__ stats) {
+// The reference's sums are sequential fp32 chains over the interior in row-major order (hmath.h:43-60): 4 M dependent additions
+// per 2000 x 2000 pair and chain, which no reduction tree may reorder.  What can be saved is everything AROUND the additions.
+// Two waves per pair, one chain each (wave 0: sum x, wave 1: sum x*x), and the running value travels through the lanes:
+//     s = wave_ror:1(s) + x          one v_add_f32_dpp per element
+// — after step k the true partial sum sits in lane k mod 64, having just added that lane's own element; all other lanes compute
+// values nobody reads.  No v_readlane, no SGPR round trip: the chain is one dependent VALU instruction per element (a lone wave
+// issues one every ~2 ns), 8 x 64 elements are in flight while the previous 512 are consumed.
+__device__ __forceinline__ float ror1_add(float s, float x) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(s), 0x13C, 0xF, 0xF, false)) + x;   // wave_ror:1
+}
+
+__global__ __launch_bounds__(128) void hmap2_stats_kernel(const PairDesc* __restrict__ pairs, const float* __restrict__ Sbase,
+                                                          float* __restrict__ stats) {
+  __shared__ float s_total[2];
   const PairDesc pd = pairs[blockIdx.x];
   const float* S = Sbase + pd.plane_off;
-  const int Q = pd.Q, T = pd.T, ld = pd.ld, lane = threadIdx.x;
+  const int Q = pd.Q, T = pd.T, ld = pd.ld, lane = threadIdx.x & 63;
+  const bool squares = (threadIdx.x >> 6) != 0;          // wave-uniform: this wave's chain
   int i0 = 1, i1 = Q - 1, j0 = 1, j1 = T - 1;
   if (i0 >= i1 || j0 >= j1) { i0 = 0; j0 = 0; i1 = Q; j1 = T; }   // hmath.h:65-66
-  float sum = 0.f, sumsq = 0.f;
-  // The two chains are inherently serial (fp32 sums in the reference's row-major order); what can be hidden is the
-  // memory latency: 8 x 64 elements are in flight while the previous 512 are being added.
   const int W = j1 - j0, N = (i1 - i0) * W;
   constexpr int kU = 8;
   float v[kU];
@@ -156,32 +166,32 @@ __global__ __launch_bounds__(64) void hmap2_stats_kernel(const PairDesc* __restr
       v[u] = (n < N) ? S[(size_t)(i0 + n / W) * ld + j0 + n % W] : 0.f;
     }
   };
+  float s = 0.f;
   fetch(0);
   for (int base = 0; base < N; base += 64 * kU) {
     float cv[kU];
 #pragma unroll
-    for (int u = 0; u < kU; ++u) cv[u] = v[u];
+    for (int u = 0; u < kU; ++u) cv[u] = squares ? v[u] * v[u] : v[u];
     if (base + 64 * kU < N) fetch(base + 64 * kU);
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
-      const float sq = cv[u] * cv[u];
       const int cnt = min(64, N - (base + 64 * u));
       if (cnt == 64) {
 #pragma unroll
-        for (int l = 0; l < 64; ++l) {                  // the reference's order: one element at a time
-          sum += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cv[u]), l));
-          sumsq += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sq), l));
-        }
+        for (int l = 0; l < 64; ++l) s = ror1_add(s, cv[u]);      // element l is added by lane l at step l
       } else {
-        for (int l = 0; l < cnt; ++l) {
-          sum += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cv[u]), l));
-          sumsq += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sq), l));
-        }
+        for (int l = 0; l < cnt; ++l) s = ror1_add(s, cv[u]);
       }
     }
   }
-  if (lane == 0) {
+  // the chain's value sits in the lane that added the last element
+  const int last_lane = N > 0 ? (N - 1) & 63 : 0;
+  const float mine = __shfl(s, last_lane);
+  if (lane == 0) s_total[squares ? 1 : 0] = N > 0 ? mine : 0.f;
+  __syncthreads();
+  if (threadIdx.x == 0) {
     const float n = (float)((i1 - i0) * (j1 - j0));
+    const float sum = s_total[0], sumsq = s_total[1];
     float avg = sum / n;
     float var = sumsq / n - avg * avg;
     float sd = sqrtf(var);
@@ -233,7 +243,7 @@ int launch_sim_hmap2(aln_batch* b, const aln_sim* sim) {
                      dt_conf, b->d_S, sim->alpha);
   HTRY(hipGetLastError());
   if (sim->normalize) {
-    hipLaunchKernelGGL(hmap2_stats_kernel, dim3(b->n_pairs), dim3(64), 0, ctx->stream, b->d_pairs, b->d_S, d_stats);
+    hipLaunchKernelGGL(hmap2_stats_kernel, dim3(b->n_pairs), dim3(128), 0, ctx->stream, b->d_pairs, b->d_S, d_stats);
     HTRY(hipGetLastError());
     dim3 g3((b->maxT + 255) / 256, b->maxQ, b->n_pairs);
     hipLaunchKernelGGL(hmap2_apply_kernel, g3, dim3(256), 0, ctx->stream, b->d_pairs, b->d_S, d_stats, -sim->zero_shift);

@@ -258,12 +258,20 @@ int aln_batch_optimal_enqueue(aln_batch* b);
 int aln_batch_optimal_collect(aln_batch* b, float* scores, int32_t* n, int32_t* status);
 /* Optimal + AlignmentSet::assignIdentity + SequenceGaps for every pair: what a driver prints for
  * `AlignmentSet as(dpm, optimal); as.assignIdentity(); cout << FastaOut(len) << as` (aa_ali.cpp:83-92, fastaio.h:51-76,
- * gstrings.h:84-164), without the FASTA framing.  Device: find_max + traceback; the pair lists are copied to the host and the
- * gapped lines built there.  tlines / qlines: n_pairs x stride chars, NUL-terminated (stride > T + Q covers any alignment);
- * lengths[p] = line length (0: status[p] != 0, or a list SequenceGaps cannot print).  scores/identity/status/lengths may be NULL.
- * This is the end-to-end readout of config 2 (pair lists D2H + strings); aln_batch_optimal_enqueue/_collect is the score-only one. */
+ * gstrings.h:84-164, alignment.h:856-865), without the FASTA framing.  Device: find_max + traceback, then one wave per pair lays
+ * the template / query lines out and counts the identities (csrc/gapped_strings.hip); only the lines travel to the host.
+ * tlines / qlines: n_pairs x stride chars, NUL-terminated (stride > T + Q covers any alignment); lengths[p] = line length
+ * (0: status[p] != 0, or a list SequenceGaps cannot print).  scores/identity/status/lengths may be NULL.  Returns ALN_E_OVERFLOW when
+ * a line does not fit the stride.  This is the end-to-end readout of config 2; aln_batch_optimal_enqueue/_collect is the score-only one. */
 int aln_batch_optimal_strings(aln_batch* b, float* scores, float* identity, int32_t* status, char* tlines, char* qlines,
                               int32_t stride, int32_t* lengths);
+/* The same, split like aln_batch_optimal_enqueue / _collect: _enqueue launches find_max + traceback + the string kernel on the
+ * context's stream and the copy of the lines into one of two pinned slots on a separate copy stream, and returns at once
+ * (ALN_E_STATE when both slots are waiting); _collect waits for the OLDEST slot and fills the caller's buffers (same `stride`).
+ * `dp; strings_enqueue; strings_collect(previous)` overlaps step k's copy and host work with step k+1's kernels. */
+int aln_batch_optimal_strings_enqueue(aln_batch* b, int32_t stride);
+int aln_batch_optimal_strings_collect(aln_batch* b, float* scores, float* identity, int32_t* status, char* tlines, char* qlines,
+                                      int32_t stride, int32_t* lengths);
 /* Optimal_Subali::enumerate (optimal_subali.h:60-84) on the rectangles of the last aln_batch_dp_sub. */
 int aln_batch_optimal_subali(aln_batch* b, float* scores, int32_t* n, int32_t* pairs,
                              int32_t pair_stride, int32_t* status);
@@ -358,6 +366,10 @@ int aln_hmap2_gap_arrays(const float* t_sse, int64_t n, float gap_init, float ga
                          float* t_gap_init, float* t_gap_extn);
 
 /* ---- measurement hooks ---------------------------------------------------------------------- */
+/* Context hint "exact_debug" = 1: the exact-order tiled kernel (config 3) counts, per wave, the far candidate chunks it tested
+ * against their bounds and the ones it could skip: out4 = {deletion chunks tested, skipped, insertion chunks tested, skipped}.
+ * (No reference counterpart: the reference scans every candidate, dpmatrix.h:453-480.) */
+int aln_batch_last_exact_stats(const aln_batch* b, uint64_t* out4);
 /* Milliseconds the device spent in the DP kernel(s) of the last aln_batch_dp, from HIP events recorded on
  * the ctx stream around those launches; synchronises the stream. */
 int aln_batch_last_dp_ms(aln_batch* b, float* ms);

@@ -42,3 +42,14 @@ def strings_for(q, t, lists):
         a = np.ascontiguousarray(np.asarray(p, np.int32).reshape(-1))
         idn.append(np.float32(L.aln_identity(qs, len(qs), ts, len(ts), a.ctypes.data_as(C.POINTER(C.c_int32)), len(a) // 2)))
     return tl.value.decode(), qls, idn
+
+
+def identity_for(q, t, pairs):
+    """calcIdentity of one pair list via the C ABI host helper."""
+    L = aln_amd.lib()
+    qs, ts = ("^" + q + "$").encode(), ("^" + t + "$").encode()
+    a = np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1))
+    if len(a) == 0:
+        a = np.zeros(2, np.int32)
+        return np.float32(L.aln_identity(qs, len(qs), ts, len(ts), a.ctypes.data_as(C.POINTER(C.c_int32)), 0))
+    return np.float32(L.aln_identity(qs, len(qs), ts, len(ts), a.ctypes.data_as(C.POINTER(C.c_int32)), len(a) // 2))

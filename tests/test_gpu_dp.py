@@ -350,6 +350,76 @@ def test_blocked_exact_kernel_long_rows(direction, blosum62):
         b.close()
 
 
+@pytest.mark.parametrize("direction", ["fwd", "rev"])
+def test_exact_chunk_skipping_is_invisible(direction, blosum62):
+    """dp_exact_tiled_kernel skips far chunks of candidates that provably cannot matter (nearest chunk first, block maxima as
+    bounds, a rounding margin — csrc/dp_exact_blocked.hip).  On pairs with dozens of row blocks and several column tiles: the
+    planes with the skipping on equal the planes with it off AND the oracle's, bit for bit, pointers included — fractional
+    constant gaps and integer gaps (ties everywhere) over BLOSUM scores, position-minimum gaps over fractional planes; global,
+    local, semi-local; the counters show that chunks really were skipped."""
+    alpha, table = blosum62
+    d = DIRS[direction]
+    od = orc.FWD if direction == "fwd" else orc.REV
+    ctx = gpu_util.ctx()
+    shapes = [(620, 900), (1100, 530), (300, 1400)]
+    pairs = []
+    for n, (ql, tl) in enumerate(shapes):
+        q, t = homolog_pair(83000 + n, max(ql, tl), sub_rate=0.3, indel=6)
+        pairs.append((q[:ql], t[-tl:]))
+    for mode, gi, ge, algo in ((1, 4.73, 0.34, aln_amd.DP_AUTO), (3, 11, 1, aln_amd.DP_EXACT), (4, 2.5, 0.25, aln_amd.DP_AUTO)):
+        got = {}
+        for prune in (1, 0):
+            with ctx.hints(exact_prune=prune, exact_debug=1):
+                b = aln_amd.Batch(ctx, [p[0] for p in pairs], [p[1] for p in pairs])
+                b.dp_submatrix(alpha, table, mode, gi, ge, d, algo)
+                assert "dp_exact_tiled" in b.kernel_name()
+                got[prune] = [b.get_cells(p) for p in range(len(pairs))]
+                st = b.last_exact_stats()
+                if prune:
+                    assert st[1] > 0 and st[3] > 0 and st[1] <= st[0] and st[3] <= st[2], st      # chunks really were skipped
+                b.close()
+        for p, (q, t) in enumerate(pairs):
+            for x, y in zip(got[1][p], got[0][p]):
+                assert np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32)), (mode, p, direction)
+            S = orc.sim_submatrix(q, t, alpha, table)
+            rc, D0, PQ0, PT0 = orc.dp_build(S, orc.Gap(mode, gi, ge), od)
+            D, PQ, PT = got[1][p]
+            assert np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (mode, p, direction)
+            assert np.array_equal(PQ, PQ0) and np.array_equal(PT, PT0), (mode, p, direction)
+    # position-minimum gaps over fractional planes (the config-3 model)
+    rng = np.random.RandomState(13)
+    dims = [(700, 1000), (420, 1500)]
+    planes, tgis, tges = [], [], []
+    for (Q, T) in dims:
+        S = rng.normal(-0.12, 1.0, size=(Q, T)).astype(np.float32)
+        S[0, :] = 0; S[-1, :] = 0; S[:, 0] = 0; S[:, -1] = 0
+        planes.append(S)
+        pi = np.exp(rng.uniform(-0.25, 1.0, size=T)).astype(np.float32)
+        tgis.append((np.float32(4.73) * pi).astype(np.float32))
+        tges.append((np.float32(0.34) * pi).astype(np.float32))
+    for mode in (1, 3, 4):
+        got = {}
+        for prune in (1, 0):
+            with ctx.hints(exact_prune=prune, exact_debug=1):
+                b = aln_amd.Batch(ctx, ["A" * (Q - 2) for Q, T in dims], ["A" * (T - 2) for Q, T in dims])
+                b.dp_simmatrix(planes, mode, 0, 0, d, tgi=np.concatenate(tgis), tge=np.concatenate(tges))
+                assert "dp_exact_tiled" in b.kernel_name()
+                got[prune] = [b.get_cells(p) for p in range(len(dims))]
+                st = b.last_exact_stats()
+                if prune:
+                    assert st[1] > 0 and st[3] > 0 and st[1] <= st[0] and st[3] <= st[2], st
+                else:
+                    assert st[0] == 0 and st[2] == 0, st               # nothing is tested when the skipping is off
+                b.close()
+        for p, S in enumerate(planes):
+            for x, y in zip(got[1][p], got[0][p]):
+                assert np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32)), (mode, p, direction)
+            rc, D0, PQ0, PT0 = orc.dp_build(S, orc.Gap(mode, tgi=tgis[p], tge=tges[p]), od)
+            D, PQ, PT = got[1][p]
+            assert np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (mode, p, direction)
+            assert np.array_equal(PQ, PQ0) and np.array_equal(PT, PT0), (mode, p, direction)
+
+
 def test_full_size_three_kernels_agree(blosum62):
     """BASELINE config-2/3 sizes (2000 x 2000): the tagged O(n^2) kernel, the int O(n^2) kernel and the exact-order O(n^3)
     kernel are three independent programmes for the same recurrence; on integer gaps their score and pointer planes must
@@ -722,6 +792,50 @@ def test_optimal_strings_equal_the_reference(blosum62):
             assert goldens.f32bits(scores[k]) == ref["alis"][0]["score"], c["name"]
             assert goldens.f32bits(ident[k]) == ref["alis"][0]["identity"], c["name"]
             assert tl[k] == ref["tstr"] and ql[k] == ref["alis"][0]["qstr"], c["name"]
+        b.close()
+
+
+@pytest.mark.parametrize("direction", ["fwd", "rev"])
+def test_device_strings_equal_the_host_renderer(direction, blosum62):
+    """csrc/gapped_strings.hip (one wave per pair lays out both lines and counts identities on the device) against the host
+    renderer aln_gapped_strings / aln_identity (pinned by every golden set) fed with the same batch's pair lists: all five align
+    types, both build directions (reverse local lists may be unprintable: empty lines on both routes), ragged sizes from empty
+    sequences to pairs with end jumps of hundreds of columns (written wave-wide), and the enqueue / collect form with both slots
+    in flight."""
+    alpha, table = blosum62
+    pairs = [random_pair(61000 + n, ql, tl) for n, (ql, tl) in enumerate([(0, 0), (1, 1), (1, 40), (33, 2), (64, 64), (150, 700), (700, 130), (257, 255)])]
+    pairs += [homolog_pair(61100 + n, ln, sub_rate=0.2, indel=6) for n, ln in enumerate((40, 130, 420, 900))]
+    pairs += [("ACDEFGHIKL", "ACDEFGHIKL"), ("AAAAAAAAAAAAAAAAAAAAWWWWWWWWWWWW", "WWWWWWWWWWWWCCCCCCCCCCCCCCCCCCCCCCCCCCCCCC")]
+    qs, ts = [p[0] for p in pairs], [p[1] for p in pairs]
+    ctx = gpu_util.ctx()
+    for mode, gi, ge in ((3, 11, 1), (1, 11, 1), (0, 11, 1), (2, 11, 1), (4, 4.73, 0.34)):
+        b = aln_amd.Batch(ctx, qs, ts)
+        b.dp_submatrix(alpha, table, mode, gi, ge, DIRS[direction])
+        sc0, lists, st0 = b.optimal()
+        scores, ident, status, tl, ql = b.optimal_strings()
+        b.optimal_strings_enqueue()                                    # both slots in flight, collected oldest first
+        b.optimal_strings_enqueue()
+        again = [b.optimal_strings_collect(), b.optimal_strings_collect()]
+        printed = 0
+        for k, (q, t) in enumerate(pairs):
+            assert status[k] == st0[k] and np.float32(scores[k]).view(np.uint32) == np.float32(sc0[k]).view(np.uint32), (mode, k)
+            if st0[k] != 0:
+                assert tl[k] == "" and ql[k] == "" and ident[k] == 0, (mode, k)
+                continue
+            pl = lists[k]
+            Q, T = len(q) + 2, len(t) + 2
+            printable = len(pl) > 0 and tuple(pl[-1]) == (Q - 1, T - 1) and all(tuple(pl[i]) != tuple(pl[i - 1]) for i in range(1, len(pl)))
+            assert np.float32(ident[k]).view(np.uint32) == gpu_util.identity_for(q, t, pl).view(np.uint32), (mode, k)
+            if not printable:
+                assert tl[k] == "" and ql[k] == "", (mode, k)
+                continue
+            want_t, want_q, _ = gpu_util.strings_for(q, t, [pl])
+            assert tl[k] == want_t and ql[k] == want_q[0], (mode, direction, k, tl[k], want_t)
+            printed += 1
+        assert printed >= (len(pairs) - 2 if direction == "fwd" else 1)
+        for got in again:
+            assert np.array_equal(got[0].view(np.uint32), scores.view(np.uint32)) and np.array_equal(got[1].view(np.uint32), ident.view(np.uint32))
+            assert got[3] == tl and got[4] == ql
         b.close()
 
 

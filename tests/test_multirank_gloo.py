@@ -117,3 +117,36 @@ def test_two_rank_gather_equals_single_process():
         rc, D, PQ, PT = orc.dp_build(S, orc.Gap(orc.LOCAL, 11, 1))
         want.append(float(orc.optimal(D, PQ, PT, True)[1]))
     assert got == want
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher in the environment: the parent starts two rank processes of itself before any
+    GPU call, they rendezvous on 127.0.0.1, rotate their launches, gather ONCE per step, agree on the batch shape, and rank 0's
+    single JSON line comes back on the parent's stdout with exit code 0.  ALN_BENCH_REHEARSE=cpu replaces the resident batches by
+    stand-ins (no GPU here) — the control flow around them is the one the GPU run uses."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["ALN_BENCH_REHEARSE"] = "cpu"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "8",
+                        "--streams", "2", "--split", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.split("\n") if l.strip()]
+    assert len(lines) == 1, r.stdout
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["steps"] == 3 and doc["scaling"] == "weak" and "rehearsal" in doc
+    assert doc["config"]["gathers"] == 4 and doc["config"]["launches_per_step"] == 2        # warmup + steps gathers, not one per launch
+
+
+def test_bench_ranks_that_disagree_fail_instead_of_hanging():
+    """Two ranks started by hand with different --pairs: the agreement step before the first collective ends both."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r, pairs in enumerate(("8", "16")):
+        env = dict(os.environ, ALN_BENCH_REHEARSE="cpu", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", pairs,
+                                       "--streams", "1", "--split", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode != 0 for p in procs), outs
+    assert any("disagree" in o[1] for o in outs), outs

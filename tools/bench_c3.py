@@ -34,6 +34,10 @@ def main():
     inner = n * (L + 2) ** 2 * (2 * L + 4) / 2.0
     print("config3 %d pairs %dx%d mode %d: sim+dp %.3f s (DP kernel %.1f ms), traceback %.3f s; %.3f GCUPS, %.1f G inner-k evals/s; %s; score[0]=%.4f len=%d"
           % (n, L, L, mode, t1 - t0, dp_ms, t2 - t1, n * L * L / (t1 - t0) / 1e9, inner / (dp_ms * 1e-3) / 1e9, b.kernel_name(), scores[0], len(lists[0])))
+    if os.environ.get("ALN_EXACT_DEBUG"):
+        st = b.last_exact_stats()
+        print("  far chunks per wave: deletions tested %d skipped %d (%.3f); insertions tested %d skipped %d (%.3f); ALN_EXACT_PRUNE=%s"
+              % (st[0], st[1], st[1] / max(st[0], 1), st[2], st[3], st[3] / max(st[2], 1), os.environ.get("ALN_EXACT_PRUNE", "1")))
 
 
 if __name__ == "__main__":
