@@ -176,6 +176,7 @@ void aln_batch_destroy(aln_batch* b) {
   hipFree(b->d_res); hipFree(b->d_table32); hipFree(b->d_tablef); hipFree(b->d_tgi); hipFree(b->d_tge);
   hipFree(b->d_path); hipFree(b->d_bounds); hipFree(b->d_xscratch); hipFree(b->d_tagq); hipFree(b->d_tagstate); hipFree(b->d_deltabR); hipFree(b->d_pair_deloff);
   aln::free_string_buffers(b);
+  if (b->stage_ev) hipEventDestroy(b->stage_ev);
   if (b->h_stage_pin) hipHostFree(b->h_stage_pin);
   for (auto& sc : b->enum_scratch) hipFree(sc.p);
   hipFree(b->d_tcn); hipFree(b->d_deltab); hipFree(b->d_deltab_off); hipFree(b->d_instab);
@@ -236,7 +237,10 @@ int upload_submatrix(aln_batch* b, const aln_submatrix* sub) {
     ALN_HIP_CHECK(ctx, hipHostMalloc((void**)&b->h_stage_pin, need, hipHostMallocDefault));
     b->h_stage_bytes = need;
   }
-  ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // an earlier upload may still read the staging buffer
+  // an earlier upload may still read the staging buffer: wait for ITS copies (an event behind them), not for the kernels that
+  // followed them on the stream — a caller that pipelines builds would stall here for a whole DP kernel
+  if (b->stage_ev) ALN_HIP_CHECK(ctx, hipEventSynchronize(b->stage_ev));
+  else ALN_HIP_CHECK(ctx, hipEventCreateWithFlags(&b->stage_ev, hipEventDisableTiming));
   uint8_t* qc = b->h_stage_pin;
   uint8_t* tc = qc + nq;
   float* tf = reinterpret_cast<float*>(b->h_stage_pin + ((nq + nt + 15) & ~(size_t)15));
@@ -282,6 +286,7 @@ int upload_submatrix(aln_batch* b, const aln_submatrix* sub) {
   ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_tcodes, tc, nt, hipMemcpyHostToDevice, ctx->stream));
   ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_tablef, tf, sizeof(float) * 1024, hipMemcpyHostToDevice, ctx->stream));
   ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_table32, ti, sizeof(int32_t) * 1024, hipMemcpyHostToDevice, ctx->stream));
+  ALN_HIP_CHECK(ctx, hipEventRecord(b->stage_ev, ctx->stream));
   return ALN_OK;             // (the staging buffer lives with the batch: no wait here, the launch follows on the same stream)
 }
 
@@ -423,6 +428,7 @@ static int prepare_dp(aln_batch* b, const aln_sim* sim, const aln_gap* gap, int3
   b->algo = algo;
   b->bug_b4 = bug_b4;
   b->islocal = gap->dp_local == 0 ? (gap->align_type == ALN_LOCAL) : (gap->dp_local == 2);   // dpmatrix.h:155
+  if (b->have_sub) b->pairs_dirty = true;                           // the device still holds the last sub-rectangles
   b->have_sub = false;
   for (PairDesc& d : b->h_pairs) { d.q0 = 0; d.q1 = d.Q - 1; d.t0 = 0; d.t1 = d.T - 1; }
   b->gapdev.model = gap->model;
@@ -439,13 +445,19 @@ static int prepare_dp(aln_batch* b, const aln_sim* sim, const aln_gap* gap, int3
   else if (sim->kind == ALN_SIM_HMAP2) {
     // Hmap2Eval: SimilarityMatrix + post_process computed on the device into the resident plane, then a plain plane build
     ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_pairs, b->h_pairs.data(), sizeof(PairDesc) * b->n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    b->pairs_dirty = false;
     rc = launch_sim_hmap2(b, sim);
     if (rc) return rc;
     b->sim_kind = ALN_SIM_MATRIX;
   }
   else return ALN_E_ARG;
   b->gap.t_gap_init = nullptr; b->gap.t_gap_extn = nullptr;        // host pointers are not retained
-  if (b->n_pairs) ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_pairs, b->h_pairs.data(), sizeof(PairDesc) * b->n_pairs, hipMemcpyHostToDevice, ctx->stream));
+  // the descriptors on the device are the full-rectangle ones the batch was created with unless a sub-rectangle build or a table
+  // model rewrote them: an H2D copy from pageable memory stalls a pipelined caller, so it is made only then
+  if (b->n_pairs && b->pairs_dirty) {
+    ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_pairs, b->h_pairs.data(), sizeof(PairDesc) * b->n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    b->pairs_dirty = false;
+  }
   *integral_out = integral;
   return ALN_OK;
 }
@@ -518,6 +530,7 @@ int aln_batch_dp_sub(aln_batch* b, const aln_sim* sim, const aln_gap* gap, int32
     d.q0 = bounds[4 * p]; d.t0 = bounds[4 * p + 1]; d.q1 = bounds[4 * p + 2]; d.t1 = bounds[4 * p + 3];
   }
   b->have_sub = true;
+  b->pairs_dirty = true;
   aln_ctx* ctx = b->ctx;
   ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->d_pairs, b->h_pairs.data(), sizeof(PairDesc) * b->n_pairs, hipMemcpyHostToDevice, ctx->stream));
   return run_dp(b, false);

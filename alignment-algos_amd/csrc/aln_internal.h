@@ -149,6 +149,8 @@ struct aln_batch {
   float enum_search_ms = 0.f, enum_unroll_ms = 0.f;   // last aln_batch_enumerate_all
   // device pools of aln_batch_enumerate_all, kept between calls (hint enum_keep_pools): a hipMalloc of tens of GB costs seconds
   uint8_t* h_stage_pin = nullptr; size_t h_stage_bytes = 0;   // pinned staging of residue codes + table (upload_submatrix)
+  hipEvent_t stage_ev = nullptr;                              // ... behind the last upload's copies out of it
+  bool pairs_dirty = false;                                   // d_pairs differs from the full-rectangle descriptors in h_pairs
   struct Scratch { void* p = nullptr; size_t bytes = 0; };
   Scratch enum_scratch[9];
   std::vector<int32_t> enum_usage;                    // ... and what every pair's search used of its pools

@@ -30,6 +30,7 @@ sys.path.insert(0, os.path.join(ROOT, "alignment-algos_amd"))
 
 import numpy as np  # noqa: E402
 
+CAL_STEPS = 10          # steps of one calibration region (bench.py picks the launch pattern and the kernel build before the warmup)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300-6900 GB/s is what a plain fill reaches
 # gfx950 VALU issue, measured with tools/valu_rate2.hip / valu_occ.hip: ns per wave64 instruction and SIMD with >= 2 waves issuing
 VALU_NS_FULL, VALU_NS_HALF = 0.92, 1.58
@@ -186,7 +187,7 @@ def secondary_configs(aln_amd, ctx, alphabet, table, qs, ts, length):
         ln = 400 + int(g.draw(1)[0] % 201)
         seqs.append(residues(g, ln))
     pool = aln_amd.SeqPool(seqs)
-    aln_amd.score_all_vs_all(ctx, pool, pool, alphabet, table, 11, 1, 0, 32)
+    aln_amd.score_all_vs_all(ctx, pool, pool, alphabet, table, 11, 1, 0, 512)     # (same shape as the timed call: pools, code objects)
     t0 = time.perf_counter()
     aln_amd.score_all_vs_all(ctx, pool, pool, alphabet, table, 11, 1, 0, 512)
     dt = time.perf_counter() - t0
@@ -194,6 +195,27 @@ def secondary_configs(aln_amd, ctx, alphabet, table, qs, ts, length):
     out["c5"] = {"workload": "config 5, one of 8 ranks' share: 512 query rows x 4096 templates of the 4096-sequence set (400-600 aa), "
                              "local 11/1, scores only; residue upload and score download included",
                  "value": round(cells / dt / 1e9, 1), "unit": "GCUPS", "seconds": round(dt, 4), "bound": "valu"}
+    # second roof of these VALU-bound kernels: wave-instructions (SQ_INSTS_VALU of the r03_sec profile set, same workloads) over the
+    # kernels' time in THIS run, against the measured full-rate issue of 1024 SIMDs (one wave64 instruction per 0.92 ns and SIMD)
+    pfile = os.path.join(ROOT, "profiles", "pmc_secondary.json")
+    if os.path.exists(pfile) and n == 1024 and length == 2000:
+        try:
+            pj = json.load(open(pfile))
+            peak = N_SIMD / (VALU_NS_FULL * 1e-9) / 1e12                           # T wave-instructions / s
+            c3i = sum(k["valu_insts_per_call"] for k in pj["c3"])
+            out["c3"]["roofline"] = {"bound": "valu", "achieved": round(c3i / (out["c3"]["dp_kernel_ms"] * 1e-3) / 1e12, 4), "peak": round(peak, 4),
+                                     "unit": "T wave64 VALU instructions/s", "frac": round(c3i / (out["c3"]["dp_kernel_ms"] * 1e-3) / 1e12 / peak, 4),
+                                     "valu_insts_per_call": c3i, "kernel_ms": out["c3"]["dp_kernel_ms"], "source": pj["source"]}
+            c5i = sum(k["valu_insts_per_call"] for k in pj["c5"])
+            out["c5"]["roofline"] = {"bound": "valu", "achieved": round(c5i / out["c5"]["seconds"] / 1e12, 4), "peak": round(peak, 4),
+                                     "unit": "T wave64 VALU instructions/s", "frac": round(c5i / out["c5"]["seconds"] / 1e12 / peak, 4),
+                                     "valu_insts_per_call": c5i, "seconds": out["c5"]["seconds"], "source": pj["source"],
+                                     "note": "time = the whole call (uploads and the score download included)"}
+            c4i = sum(k["valu_insts_per_call"] for k in pj["c4"])
+            out["c4"]["roofline"] = {"bound": "latency (dependent memory round trips)", "valu_frac": round(c4i / (out["c4"]["search_kernel_ms"] * 1e-3) / 1e12 / peak, 4),
+                                     "valu_insts_per_call": c4i, "source": pj["source"]}
+        except Exception:
+            pass
     return out
 
 
@@ -451,7 +473,7 @@ def rank_main(args):
 
     # ---- calibration (untimed, before the warmup): the launch pattern and the build of the kernel this box prefers -----------------
     # {4 streams x 2 launches per step, 2 streams x 1, one lone launch} x {two, three waves per SIMD} x {row-alternating priority
-    # off, on}: 5 steps each after one settling step, two interleaved passes; the fastest runs the warmup and the timed region.
+    # off, on}: CAL_STEPS steps each after one settling step, two interleaved passes; the fastest runs the warmup and the timed region.
     # A caller that keeps batches resident would tune exactly so; boxes of the pool differ (the same build: 2.7 - 3.3 ms per step).
     calib = None
     plan = plans[0]
@@ -467,11 +489,11 @@ def rank_main(args):
                             pl.set_variant(occ, ap)
                             pl.step(); pl.drain(); fence()
                             t0 = time.perf_counter()
-                            for _ in range(5):
+                            for _ in range(CAL_STEPS):
                                 pl.step()
                             pl.drain(); fence()
                             key = (pi, occ, ap)
-                            best_of[key] = min((time.perf_counter() - t0) / 5 * 1e3, best_of.get(key, 1e9))
+                            best_of[key] = min((time.perf_counter() - t0) / CAL_STEPS * 1e3, best_of.get(key, 1e9))
             if world > 1:                                   # every rank must run the same build: the slowest rank's view decides
                 keys = sorted(best_of)
                 tt = torch.tensor([best_of[k] for k in keys], dtype=torch.float64, device="cpu" if rehearse else dev)
@@ -480,21 +502,23 @@ def rank_main(args):
             choice = min(best_of, key=best_of.get)
             name = lambda k: "streams%d_split%d_occ%d_altprio%d" % (plans[k[0]].nb, plans[k[0]].split, k[1], k[2])   # noqa: E731
             calib = {"ms_per_step": {name(k): round(v, 3) for k, v in sorted(best_of.items())}, "chosen": name(choice),
-                     "steps_each": 5, "passes": 2, "note": "5-step regions carry their own fill and drain: they rank the variants, "
+                     "steps_each": CAL_STEPS, "passes": 2, "note": "short regions carry their own fill and drain: they rank the variants, "
                      "they are not the result"}
         else:
             choice = (0, occs[0], aps[0])
         plan = plans[choice[0]]
         plan.set_variant(choice[1], choice[2])
-        for pl in plans:
-            if pl is not plan:
-                pl.close()
+        # (the other plans stay resident until the timed region is over: freeing tens of GB here would idle the GPU for a few
+        # hundred ms right before the warmup, and W warmup steps are too few to bring its clocks back)
     nb, split, ph = plan.nb, plan.split, plan.ph
     units = plan.units
     batches = list(units.values())
     batch = batches[0]
     calib_steps = steps_run[0]
 
+    import gc
+    gc.collect()
+    gc.disable()                                            # no collector pause inside the timed region
     for _ in range(args.warmup):
         plan.step()
     plan.drain()
@@ -508,6 +532,10 @@ def rank_main(args):
     plan.drain()
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
+    for pl in plans:
+        if pl is not plan:
+            pl.close()
     sc, status = plan.last[:2]
     assert sc is not None and (status == 0).all()
     assert not plan.open_steps and steps_run[0] == calib_steps + args.warmup + args.steps
@@ -544,33 +572,6 @@ def rank_main(args):
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-
-    # ---- end to end with the SAME launch pattern (rank 0, one GPU): every launch also encodes + uploads its residues and brings
-    # the gapped lines + identities of its pairs back to the host ----------------------------------------------------------------
-    e2e_pipe = None
-    if rank == 0 and world == 1 and not args.no_secondary and not cpu_rehearsal:
-        plan.e2e = True
-        e2e_cal = {}
-        for occ, ap in ((2, 1), (3, 1), (2, 0), (3, 0)):    # the host work between launches changes how much they overlap: tune again
-            plan.set_variant(occ, ap)
-            plan.step(); plan.drain(); fence()
-            t0 = time.perf_counter()
-            for _ in range(4):
-                plan.step()
-            plan.drain(); fence()
-            e2e_cal[(occ, ap)] = (time.perf_counter() - t0) / 4 * 1e3
-        e2e_choice = min(e2e_cal, key=e2e_cal.get)
-        plan.set_variant(*e2e_choice)
-        plan.step(); plan.drain(); fence()
-        n_pipe = 10
-        t0 = time.perf_counter()
-        for _ in range(n_pipe):
-            plan.step()
-        plan.drain(); fence()
-        e2e_pipe = {"ms_per_step": (time.perf_counter() - t0) / n_pipe * 1e3, "steps": n_pipe, "result": plan.step_result,
-                    "calibration": {"occ%d_altprio%d" % k: round(v, 3) for k, v in e2e_cal.items()}, "chosen": "occ%d_altprio%d" % e2e_choice}
-        assert np.array_equal(plan.step_result[0].view(np.uint32), all_sc.view(np.uint32))
-        plan.e2e = False
 
     parallelism = "pair-batch sharded, %d rank(s), one RCCL all-gather of the scores per step (aln_gather_scores)" % world
     if cpu_rehearsal:
@@ -618,6 +619,34 @@ def rank_main(args):
     for bt in batches:
         bt.close()
     plan.units = {}
+    # ---- end to end, pipelined (rank 0, one GPU): three resident batches of all the pairs take turns, one launch sequence each;
+    # every launch also encodes + uploads its residues and brings the gapped lines + identities of its pairs back to the host -------
+    e2e_pipe = None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        ep = Plan(3, 1)
+        ep.e2e = True
+        e2e_cal = {}
+        for occ, ap in ((2, 1), (3, 1), (2, 0), (3, 0)):    # the host work between launches changes how much they overlap: tune again
+            ep.set_variant(occ, ap)
+            ep.step(); ep.drain(); fence()
+            t0 = time.perf_counter()
+            for _ in range(6):
+                ep.step()
+            ep.drain(); fence()
+            e2e_cal[(occ, ap)] = (time.perf_counter() - t0) / 6 * 1e3
+        e2e_choice = min(e2e_cal, key=e2e_cal.get)
+        ep.set_variant(*e2e_choice)
+        ep.step(); ep.drain(); fence()
+        n_pipe = 12
+        t0 = time.perf_counter()
+        for _ in range(n_pipe):
+            ep.step()
+        ep.drain(); fence()
+        e2e_pipe = {"ms_per_step": (time.perf_counter() - t0) / n_pipe * 1e3, "steps": n_pipe, "result": ep.step_result,
+                    "calibration": {"occ%d_altprio%d" % k: round(v, 3) for k, v in e2e_cal.items()}, "chosen": "occ%d_altprio%d" % e2e_choice}
+        assert np.array_equal(ep.step_result[0].view(np.uint32), all_sc.view(np.uint32))
+        ep.close()
+
 
     # ---- lone launches: the whole batch as ONE launch per step on ONE stream, nothing else on the GPU -----------------------------
     # kernel_only = the DP kernel's own duration (HIP events on its stream), the number `rocprofv3 --kernel-trace --stats` reports for
@@ -657,10 +686,13 @@ def rank_main(args):
                "launch rocprofv3 reproduces)" % nb)
     traffic = valu = None
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tfile) and args.length == 2000:       # only if the PMC pass was taken on exactly this launch shape
+    if os.path.exists(tfile) and args.length == 2000:       # only if a PMC pass was taken on exactly this launch shape and kernel build
         try:
-            tj = json.load(open(tfile))
-            if tj.get("launch_pairs", 1024) == ph and tj.get("kernel", bench_kernel) == bench_kernel:
+            doc = json.load(open(tfile))
+            entries = doc["shapes"] if isinstance(doc, dict) and "shapes" in doc else [doc]
+            for tj in entries:
+                if tj.get("launch_pairs", 1024) != ph or tj.get("kernel") != bench_kernel:
+                    continue
                 traffic = tj.get("hbm_bytes_per_launch")
                 if tj.get("valu_insts_per_launch"):
                     ins = float(tj["valu_insts_per_launch"]) * split          # wave-instructions per step
@@ -670,6 +702,7 @@ def rank_main(args):
                     valu = {"insts_per_step": ins, "source": tj.get("source"), "half_rate_share": half,
                             "issue_ns_per_inst_per_simd": {"full_rate": VALU_NS_FULL, "half_rate": VALU_NS_HALF, "this_mix": round(ns, 3)},
                             "issue_floor_ms_per_step": round(floor_ms, 3), "frac": round(floor_ms / (ms_per_step / 1.0), 4)}
+                break
         except Exception:
             traffic = valu = None
     hbm_frac = achieved / HBM_PEAK_GBS
@@ -711,7 +744,7 @@ def rank_main(args):
     if args.trace_steps:
         out["step_stamps_ms"] = stamps
     if rank == 0 and world == 1 and not args.no_secondary:
-        out["end_to_end"] = end_to_end(aln_amd, ctxs, qs, ts, alphabet, table, mode, gi, ge, all_sc, args.pairs, e2e_pipe, nb, split)
+        out["end_to_end"] = end_to_end(aln_amd, ctxs, qs, ts, alphabet, table, mode, gi, ge, all_sc, args.pairs, e2e_pipe, 3, 1)
         out["secondary"] = secondary_configs(aln_amd, ctxs[0], alphabet, table, qs, ts, args.length)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(qs, ts, mode, gi, ge)
@@ -730,9 +763,9 @@ def rank_main(args):
 def end_to_end(aln_amd, ctxs, qs, ts, alphabet, table, mode, gi, ge, all_sc, n_pairs, piped, nb, split):
     """SURVEY 8(d) end to end, per step: residues encoded + uploaded (host buffers handed over), DP, find_max + traceback, the gapped
     template / query lines and identities of every pair on the host (the lines are laid out on the device, csrc/gapped_strings.hip;
-    only they travel).  `piped` was measured by the caller with the main region's launch pattern (sub-batches rotating over
-    streams: step k's copy and host work overlap step k+1's encoding, upload and kernels); here the same work with nothing
-    pipelined: one batch, one stream, one call after the other."""
+    only they travel).  `piped` was measured by the caller (several resident batches taking turns: step k's copy and host work
+    overlap step k+1's encoding, upload and kernels); here the same work with nothing pipelined: one batch, one stream, one call
+    after the other."""
     c0 = ctxs[0]
     c0.set_hint("tag_alt_prio", 1)
     c0.set_hint("tag_occupancy", 0)
@@ -763,9 +796,9 @@ def end_to_end(aln_amd, ctxs, qs, ts, alphabet, table, mode, gi, ge, all_sc, n_p
         res["steps"] = piped["steps"]
         res["pipelined"] = {"ms_per_step": round(piped["ms_per_step"], 3), "steps": piped["steps"],
                             "calibration_ms": piped.get("calibration"), "kernel_build": piped.get("chosen"),
-                            "how": "the main region's launch pattern (%d stream(s) x %d launch(es) per step): aln_batch_dp, "
-                                   "aln_batch_optimal_strings_enqueue, _collect of an earlier launch — copy + host work of one launch "
-                                   "overlap the next launches" % (nb, split)}
+                            "how": "%d resident batches of all the pairs take turns, one stream each (%d launch sequence(s) per step): "
+                                   "aln_batch_dp, aln_batch_optimal_strings_enqueue, _collect of the launch %d steps back — the copy and "
+                                   "the host work of one step overlap the next steps" % (nb, split, nb)}
     else:
         res["ms_per_step"] = res["not_pipelined"]["ms_per_step"]
         res["value"] = res["not_pipelined"]["value"]
