@@ -788,6 +788,12 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   std::vector<uint32_t> info;
   std::vector<float> sc, raw;
   const int max_round = std::max(0, std::min(ctx->hints.enum_pool_retries, 3));
+  // The alignment pool never has to be larger than what the reference's own brake allows: once the set is larger than user_limit every
+  // branch is forced down the optimal path (cw.h:127-140), and only the candidates of the frames still on the stack are added —
+  // fewer than (Q + T) per frame.  A pair that overflowed its alignment slots is therefore retried until its pool has that size
+  // (beyond the enum_pool_retries rounds if need be), and then returns the user_limit-truncated set instead of ALN_E_OVERFLOW.
+  const uint64_t limit_cap64 = (uint64_t)a0.user_limit + 65536ull + (uint64_t)(b->maxQ + b->maxT) * 16ull;
+  const uint32_t limit_cap = (uint32_t)std::min<uint64_t>(limit_cap64, 0x7FFFFFFFull);
   std::vector<int32_t> again, serial_todo;
   // one group of pairs: search, sortSet, unroll.  use_par: the several-waves-per-pair kernel (cw / ucw); a pair whose set outgrows
   // user_limit comes back as kParSerial and is searched again, with the same capacities, by the one-wave kernel.
@@ -983,7 +989,10 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
     free_group();
     return ALN_OK;
   };
-  for (int round = 0; round <= max_round && !todo.empty(); ++round) {
+  for (int round = 0; !todo.empty(); ++round) {
+    if (ali_cap > limit_cap) ali_cap = limit_cap;
+    // the last round: the retries are used up and the alignment pool has reached the size user_limit bounds
+    const bool final_round = round >= max_round && (ali_cap >= limit_cap || round >= max_round + 12);
     again.clear(); serial_todo.clear();
     for (int pass = 0; pass < 2; ++pass) {                // pass 1: the pairs pass 0's several-wave search handed back
       const std::vector<int32_t>& list = pass == 0 ? todo : serial_todo;
@@ -998,11 +1007,12 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
       gmax = (ids_all.size() + (ids_all.size() + gmax - 1) / gmax - 1) / ((ids_all.size() + gmax - 1) / gmax);   // groups of equal size
       for (size_t g0 = 0; g0 < ids_all.size(); g0 += gmax) {
         const int gn = (int)std::min(gmax, ids_all.size() - g0);
-        const int rcg = run_group(ids_all.data() + g0, gn, round == max_round, pw0 ? par_waves(b, noa->kind, gn) : 0);
+        const int rcg = run_group(ids_all.data() + g0, gn, final_round, pw0 ? par_waves(b, noa->kind, gn) : 0);
         if (rcg != ALN_OK) return rcg;
       }
     }
     todo.swap(again);
+    if (final_round) break;
     if (node_cap <= (1u << 29)) node_cap *= 4;
     if (ali_cap <= (1u << 22)) ali_cap *= 4;
   }

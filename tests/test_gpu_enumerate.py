@@ -117,6 +117,47 @@ def test_enumeration_user_limit_and_overflow(blosum62, enum_waves):
 
 
 @pytest.mark.parametrize("kind", ["cw", "ucw"])
+def test_batched_enumeration_grows_to_user_limit(kind, blosum62, enum_waves):
+    """aln_batch_enumerate_all with alignment pools far too small and no pool retries left: a pair whose set outgrows its slots is
+    searched again until the pool has the size user_limit bounds, and comes back with the set the reference's brake defines
+    (cw.h:127-140: beyond user_limit every branch is forced down the optimal path) — the oracle's set, not ALN_E_OVERFLOW."""
+    alpha, table = blosum62
+    lens = [80, 33, 110, 64]
+    pairs = [homolog_pair(64500 + n, ln, sub_rate=0.25, indel=3) for n, ln in enumerate(lens)]
+    maxT = max(len(t) for _, t in pairs) + 2
+    ctx = gpu_util.ctx()
+    b = aln_amd.Batch(ctx, [p[0] for p in pairs], [p[1] for p in pairs])
+    b.dp_submatrix(alpha, table, 1, 11, 1)
+    flags = np.zeros((len(pairs), maxT), dtype=np.uint8)
+    for p, (q, t) in enumerate(pairs):
+        flags[p, :len(t) + 2] = orc.make_subopt_regions(len(t) + 2, 3)
+    lim, nsub, delta = 40, 100000, 0.3
+    want = []
+    for p, (q, t) in enumerate(pairs):
+        S = orc.sim_submatrix(q, t, alpha, table)
+        gap = orc.Gap(1, 11, 1)
+        rc, D0, PQ0, PT0 = orc.dp_build(S, gap)
+        rc2, sc, pl = orc.optimal(D0, PQ0, PT0, False)
+        s = orc.AliSet()
+        s.push(pl, sc)
+        assert orc.enumerate_noa(kind, D0, PQ0, PT0, S, gap, flags[p, :len(t) + 2] if kind == "cw" else None, nsub, delta, s, user_limit=lim) == 0
+        want.append(s)
+    assert max(len(s) for s in want) > lim                       # the brake really acted
+    K = max(len(s) for s in want) + 2
+    with ctx.hints(enum_pool_retries=0):
+        n_out, scores, lengths, lists, status = b.enumerate_all(kind, nsub, delta, flags if kind == "cw" else None, K=K, node_cap=1 << 16,
+                                                                 ali_cap=16, user_limit=lim)
+    assert (status == 0).all(), status
+    for p, s in enumerate(want):
+        assert n_out[p] == len(s), (p, n_out[p], len(s))
+        for k in range(len(s)):
+            r = s.get(k)
+            assert scores[p, k].view(np.uint32) == r["score"].view(np.uint32), (p, k)
+            assert np.array_equal(lists[p, k, :lengths[p, k]], r["pairs"]), (p, k)
+    b.close()
+
+
+@pytest.mark.parametrize("kind", ["cw", "ucw"])
 def test_batched_enumeration_matches_oracle(kind, blosum62, enum_waves):
     """aln_batch_enumerate_all (BASELINE config 4 form): every pair of a ragged resident batch in ONE launch, per-pair
     SuboptFlags rows; set size, order, score bits and pair lists against the oracle, and against the one-pair entry."""

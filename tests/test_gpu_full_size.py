@@ -176,14 +176,21 @@ def test_c4_enumerate_all_at_full_size(waves, blosum62):
                 assert len(one) == n_out[k], k
                 for a, e in enumerate(one):
                     assert bits(e["score"]) == bits(scores[k, a]) and np.array_equal(e["pairs"], pairs[k, a, :lengths[k, a]]), (k, a)
-    # SURVEY's DELTA_RATIO 0.05: the reference finishes only the non-homolog pairs; the homologs overflow the per-pair pools
+    # SURVEY's DELTA_RATIO 0.05: the reference finishes only the non-homolog pairs (std::bad_alloc on the homologs).  The library
+    # grows a pair's alignment pool up to what user_limit bounds (round 3), so a homolog either comes back with the set the
+    # reference's brake defines (cw.h:127-140; nothing to pin it against: sorted, 256 kept, the Optimal alignment on top) or — if its
+    # trie outgrows the node pools — with ALN_E_OVERFLOW
+    sc_opt, _, _ = b.optimal(want_pairs=False)
     with ctx.hints(enum_pool_retries=0):
         n_out, scores, lengths, pairs, status = b.enumerate_all("cw", 256, 0.05, flags, K=K, node_cap=1 << 23, ali_cap=1 << 14,
                                                                 raise_on_overflow=False)
     for k, p in enumerate(idx):
         if p in gold:
             if gold[p]["cw"]["0.05"] is None:
-                assert status[k] == aln_amd.E_OVERFLOW, (p, status[k])
+                assert status[k] in (0, aln_amd.E_OVERFLOW), (p, status[k])
+                if status[k] == 0:
+                    assert n_out[k] == 256 and (np.diff(scores[k, :256]) <= 0).all(), p
+                    assert bits(scores[k, 0]) == bits(sc_opt[k]) and (lengths[k, :256] > 2).all(), p
             else:
                 assert status[k] == 0
                 _check_cw_set(gold[p], "0.05", pr[k][0], pr[k][1], n_out[k], scores[k], lengths[k], pairs[k], "cw 0.05 pair %d" % p)
