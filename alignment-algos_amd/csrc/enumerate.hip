@@ -782,6 +782,12 @@ extern "C" int aln_batch_enumerate_all(aln_batch* b, const aln_noa* noa, const u
   // order of what they used then, heaviest first; results are stored per pair and do not depend on the order.
   if (!prior_nodes.empty())
     std::stable_sort(todo.begin(), todo.end(), [&](int32_t x, int32_t y) { return prior_nodes[x] > prior_nodes[y]; });
+  else if (ctx->hints.enum_heavy_first) {
+    // no history yet: the alignment's score is the cheapest hint there is — the threshold window (1 - DELTA_RATIO) * score widens
+    // with it, and related sequences (long, high-scoring paths) are the ones that branch
+    auto key = [&](int32_t p) { return b->islocal ? res[p].best : res[p].corner; };
+    std::stable_sort(todo.begin(), todo.end(), [&](int32_t x, int32_t y) { return key(x) > key(y); });
+  }
   uint32_t node_cap = node_cap_per_pair ? node_cap_per_pair : (1u << 20);
   uint32_t ali_cap = ali_cap_per_pair ? ali_cap_per_pair : 65536u;
   std::vector<int32_t> hout, sel, hlens, hlists, old_of_new;

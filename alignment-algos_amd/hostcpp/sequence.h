@@ -1,41 +1,44 @@
-// sequence.h — sequences as vectors of element pointers with '^' head and '$' tail sentinels.
-// Same surface as the reference (sequence.h:22-64, sequence.cpp:15-36): SequenceElem{index,olc,isHead,isTail},
-// Sequence<elem_t>{seq_length, seq_name, olc(i), getString()}.  Own implementation.
+// sequence.h — sequences as vectors of element pointers framed by a '^' head and a '$' tail marker.
+// The surface the reference's drivers and evaluators use (sequence.h:22-64, sequence.cpp:15-36): SequenceElem {index, olc,
+// isHead, isTail, Head, Tail}, Sequence<elem_t> {seq_length, seq_name, olc(i), getString()}.  Own implementation; the engine
+// works on the marker-framed one-letter string (aln_seqs takes exactly what getString() returns).
 #ifndef ALN_HOST_SEQUENCE_H
 #define ALN_HOST_SEQUENCE_H
+#include <sstream>      // (the reference's header hands <sstream>, <string>, <vector> and the std names on to its includers)
 #include <string>
 #include <vector>
-// standard headers the reference's sequence.h hands on to its includers
-#include <sstream>
-using namespace std;   // as the reference's sequence.h does at header scope: sources written against it name string, vector, cerr ... unqualified
+using namespace std;
 
-class SequenceElem {
- public:
-  int index;
-  char olc;
-  SequenceElem() : index(-1), olc(' ') {}
-  SequenceElem(int i, char o) : index(i), olc(o) {}
-  bool isHead() const { return olc == Head; }
-  bool isTail() const { return olc == Tail; }
+struct SequenceElem {
   static const char Head = '^';
   static const char Tail = '$';
+  SequenceElem(int position = -1, char letter = ' ') : index(position), olc(letter) {}
+  bool isHead() const { return olc == Head; }
+  bool isTail() const { return olc == Tail; }
+  bool isMarker() const { return isHead() || isTail(); }
+  int index;       // position in the framed sequence
+  char olc;        // one-letter code
 };
 
 template <class elem_t>
 class Sequence : public std::vector<elem_t> {
+  typedef std::vector<elem_t> Elems;
+
  public:
   Sequence() : seq_length(0) {}
-  unsigned int seq_length;      // length without head/tail
-  std::string seq_name;
-  char olc(int i) const { return std::vector<elem_t>::at(i)->olc; }
-  // one-letter string including the sentinels, built lazily
+  char olc(int i) const { return Elems::at(i)->olc; }
+  // the framed one-letter string; rendered on first use (a derived class that edits its elements clears seq_string)
   const std::string* getString() const {
-    if (seq_string.empty()) {
-      seq_string.reserve(this->size());
-      for (typename std::vector<elem_t>::const_iterator it = this->begin(); it != this->end(); ++it) seq_string.push_back((*it)->olc);
+    if (seq_string.empty() && !this->empty()) {
+      std::string letters(this->size(), ' ');
+      for (size_t k = 0; k < letters.size(); ++k) letters[k] = (*this)[k]->olc;
+      seq_string.swap(letters);
     }
     return &seq_string;
   }
+  std::string seq_name;
+  unsigned int seq_length;      // residues, markers not counted
+
  protected:
   mutable std::string seq_string;
 };

@@ -372,9 +372,10 @@ def rank_main(args):
         kernel.  Every step still builds, scans and traces all `pairs` pairs; every (stream, sub-batch) combination that occurs
         has its own resident planes.  nb = 1, split = 1: one lone launch per step."""
 
-        def __init__(self, nb, split):
+        def __init__(self, nb, split, borrow=None):
             self.nb, self.split, self.ph = nb, split, args.pairs // split
             self.units, self.ctxs, self.streams = {}, [], []
+            self.borrowed = borrow is not None
             self.queue = []                                 # (batch, step id, sub-batch) enqueued, not yet collected (oldest first)
             self.count = 0
             self.open_steps = {}                            # step id -> [scores of sub-batch h or None]
@@ -385,6 +386,10 @@ def rank_main(args):
                 while (j % nb, j % split) not in self.units:
                     self.units[(j % nb, j % split)] = RehearsalBatch(rank * args.pairs + (j % split) * self.ph, self.ph)
                     j += 1
+                return
+            if borrow is not None:                          # the same resident batches and streams as a plan with more of them
+                self.ctxs = borrow.ctxs[:nb]
+                self.units = {k: v for k, v in borrow.units.items() if k[0] < nb}
                 return
             self.streams = [torch.cuda.Stream(dev) for _ in range(nb)]
             self.ctxs = [aln_amd.Context(local_rank, st.cuda_stream) for st in self.streams]
@@ -449,9 +454,13 @@ def rank_main(args):
                 self.collect()
             self.count = 0
 
-        def close(self):
+        def close_units(self, keep=()):                     # (Batch.close and Context.close are idempotent: shared objects may be closed twice)
             for bt in self.units.values():
-                bt.close()
+                if not any(bt is k for k in keep):
+                    bt.close()
+
+        def close(self):
+            self.close_units()
             for c in self.ctxs:
                 c.close()
             self.units, self.ctxs = {}, []
@@ -467,9 +476,14 @@ def rank_main(args):
     if args.batches > 0 or args.split > 0:                  # the caller fixed the launch pattern
         nb0, sp0 = (args.batches if args.batches > 0 else 4), (args.split if args.split > 0 else 2)
         patterns = [(nb0, sp0 if legal(nb0, sp0) else 1)]
+    elif rehearse and not cpu_rehearsal:
+        patterns = [(2, 1)]                                 # every rank on ONE GPU: no room for every pattern of every rank
     else:
         patterns = [p for p in ((4, 2), (2, 1), (1, 1)) if legal(*p)] or [(1, 1)]
-    plans = [Plan(nb_, sp_) for nb_, sp_ in patterns]
+    plans = []
+    for nb_, sp_ in patterns:                               # the lone-launch plan runs on the first batch and stream of the two-stream plan
+        lender = next((pl for pl in plans if pl.split == sp_ and pl.nb > nb_), None)
+        plans.append(Plan(nb_, sp_, borrow=lender))
 
     # ---- calibration (untimed, before the warmup): the launch pattern and the build of the kernel this box prefers -----------------
     # {4 streams x 2 launches per step, 2 streams x 1, one lone launch} x {two, three waves per SIMD} x {row-alternating priority
@@ -533,9 +547,9 @@ def rank_main(args):
     fence()
     elapsed = time.perf_counter() - t0
     gc.enable()
-    for pl in plans:
+    for pl in plans:                                        # the planes of the plans that lost; contexts live until the end
         if pl is not plan:
-            pl.close()
+            pl.close_units(keep=list(plan.units.values()))
     sc, status = plan.last[:2]
     assert sc is not None and (status == 0).all()
     assert not plan.open_steps and steps_run[0] == calib_steps + args.warmup + args.steps
@@ -754,8 +768,9 @@ def rank_main(args):
         comm.close()
     if comm_ctx is not None:
         comm_ctx.close()
-    for c in ctxs:
-        c.close()
+    for pl in plans:
+        for c in pl.ctxs:
+            c.close()
     if world > 1:
         dist.destroy_process_group()
 

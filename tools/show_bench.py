@@ -7,6 +7,9 @@ d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 r = d["roofline"]
 print("config 2: %.3f ms/step, %.1f GCUPS on %d GPU(s); %s roof: %.0f of %.0f GB/s = %.3f (%.3f of this box's fill rate %.0f GB/s)" % (
     d["ms_per_step"], d["value"], d["n_gpus"], r["bound"], r["achieved"], r["peak"], r["frac"], r.get("frac_of_measured_fill") or 0, r.get("measured_fill_GBs_this_box") or 0))
+cal = (d.get("config") or {}).get("calibration")
+if cal:
+    print("  launch pattern / kernel build chosen on this box: %s (calibration %.3f ms per step)" % (cal["chosen"], cal["ms_per_step"][cal["chosen"]]))
 if d.get("kernel_only", {}).get("ms_per_step"):
     print("  kernel only: %.3f ms/step" % d["kernel_only"]["ms_per_step"])
 if d.get("end_to_end"):
