@@ -836,6 +836,17 @@ def test_device_strings_equal_the_host_renderer(direction, blosum62):
         for got in again:
             assert np.array_equal(got[0].view(np.uint32), scores.view(np.uint32)) and np.array_equal(got[1].view(np.uint32), ident.view(np.uint32))
             assert got[3] == tl and got[4] == ql
+        # call order: nothing to collect, a third enqueue while two slots wait, the one-call form while a slot waits
+        with pytest.raises(aln_amd.AlnError) as ei:
+            b.optimal_strings_collect()
+        assert ei.value.code == aln_amd.E_STATE
+        b.optimal_strings_enqueue()
+        b.optimal_strings_enqueue()
+        for call in (b.optimal_strings_enqueue, b.optimal_strings):
+            with pytest.raises(aln_amd.AlnError) as ei:
+                call()
+            assert ei.value.code == aln_amd.E_STATE
+        b.optimal_strings_collect(); b.optimal_strings_collect()
         b.close()
 
 
