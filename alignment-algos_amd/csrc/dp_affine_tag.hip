@@ -168,12 +168,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
     if constexpr (X == 4) { const u32x2 v = {wd[0], wd[1]}; __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, 0); }
     else { const u32x4 v = {wd[0], wd[1], wd[2], wd[3]}; __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0); }
   };
-  auto store_row = [&](int i) {
+  // groups [r0, r1) of row i.  finish_row stores the groups whose cells are final (all but group 0, whose first cell of wave w > 0
+  // arrives with the exchange) BEFORE its scans and its barrier and group 0 after them (hint tag_early_store): the row's stores
+  // reach the memory pipeline in two bursts half a row apart instead of one
+  auto store_groups = [&](int i, int r0, int r1) {
     const size_t ro = (size_t)i * ld + cb;
     const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(P + (size_t)i * ld, 0, ld * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(H16p + (size_t)i * ld, 0, ld * 2, 0x00020000);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
+      if (r < r0 || r >= r1) continue;
       // low halves of two pointer words (at KB = 16: of two whole keys): one v_perm_b32 per pair of cells
       uint32_t pw[X / 2], hw[X / 2];
 #pragma unroll
@@ -195,6 +199,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
       store_words(pw, rsP, vo16 + 2 * GW * r);
     }
   };
+  auto store_row = [&](int i) { store_groups(i, 0, R); };
   auto tab_at = [&](int qrow, int c4) -> int {
     return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(tab) + qrow + c4);
   };
@@ -202,6 +207,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
   // Finish the row held in dk[]/pf[] (complete except, for w > 0, the wave's first column which the previous wave
   // computed and passes as (dB,pB)): prefix-scan preparation for the next row, exchange, local-max tracking, store.
   auto finish_row = [&](int i, int dB, uint32_t pB, bool sync, const int4 (&xin)[NW > 1 ? NW - 1 : 1]) {
+    const bool early = R > 1 && prm.early_store;
+    if (early) store_groups(i, 1, R);
     int sk = NEGK;     // scalar carry: prefix key over this wave's earlier groups
     int ik[R];
 #pragma unroll
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
         lpos = ((uint32_t)i << 16) | (uint32_t)cfirst;
       }
     }
-    store_row(i);
+    if (early) store_groups(i, 0, 1); else store_row(i);
   };
 
   // ---- hand-off slots of the segment queue: 9 x 16 bytes per thread (dk[16], gmx[16], cvk[R], lmax, lpos), chunk-major ------
@@ -629,6 +636,7 @@ int launch_dp_affine_tag(aln_batch* b) {
   // row-alternating wave priority: a per-context hint (aln_ctx_set_hint "tag_alt_prio"): it pays while launches follow each other
   // on one stream (the arbiter's favouritism costs ~6 %) and loses when the caller overlaps launches of several contexts
   prm.alt_prio = b->ctx->hints.tag_alt_prio;
+  prm.early_store = b->ctx->hints.tag_early_store;
   prm.lag = b->ctx->hints.tag_lag;
   if (prm.lag < 0 || prm.lag > 4 || (prm.lag & (prm.lag - 1))) prm.lag = 0;      // 0, 1, 2 or 4: lag * (NW-1) + lag <= 16 slots for NW <= 4
   const int ld = b->maxld;
