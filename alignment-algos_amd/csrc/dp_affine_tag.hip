@@ -62,6 +62,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
   constexpr int RING = 16;              // exchange slots: one per row, reused every 16 rows
   __shared__ __attribute__((aligned(16))) int xch[RING][NW][4];
   __shared__ int red[NW][2];
+  __shared__ int prog[NW];              // flag exchange: the last row each wave has finished reading its neighbours' records for
 
   // ---- which pair, which rows ------------------------------------------------------------------------------------
   __shared__ int s_item;
@@ -108,6 +109,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
 
   for (int k = threadIdx.x; k < 32 * 32; k += 64 * NW) tab[k] = table32[k] * (1 << KB);
   for (int k = threadIdx.x; k < Q; k += 64 * NW) qcs[k] = qc[k];
+  if (threadIdx.x < NW) prog[threadIdx.x] = 0;
+  if (threadIdx.x < RING * NW) xch[threadIdx.x / NW][threadIdx.x % NW][3] = -1;      // row tags: no record yet
   __syncthreads();
 
   // ---- static per-column constants -----------------------------------------------------------------
@@ -230,16 +233,41 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
     }
     if (NW > 1) {
       const int slot = i & (RING - 1);
-      if (lane == 63) { xch[slot][w][0] = sk; xch[slot][w][1] = dB; xch[slot][w][2] = (int)pB; }
+      // Flag exchange (hint tag_flag_sync, synchronous mode only): the dependence runs one way — wave w needs the records of the
+      // waves before it, nobody needs anything from the waves after — so no wave has to wait at a barrier for a LATER one.  A
+      // record carries its row number in its fourth word (one 16-byte LDS write): a consumer polls until the tag is its row.
+      // The ring has 16 slots: every 8 rows a producer makes sure the later waves have read up to 8 rows back before it goes on.
+      const bool flags = sync && !SEGQ && prm.flag_sync;
+      if (flags && w < NW - 1 && (i & 7) == 0 && i >= 16) {
+#pragma unroll
+        for (int v = 1; v < NW; ++v) {
+          if (v > w) {                                      // (bounded: a broken exchange must end in wrong planes the tests catch, never in a hang)
+            for (int spin = 0; spin < (1 << 24) && __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(&prog[v])) < i - 8; ++spin)
+              __builtin_amdgcn_s_sleep(0);
+          }
+        }
+      }
+      if (lane == 63) {
+        xch[slot][w][0] = sk; xch[slot][w][1] = dB; xch[slot][w][2] = (int)pB;
+        if (flags) {                                        // the tag goes last (a wave's LDS operations are served in order)
+          asm volatile("" ::: "memory");
+          *reinterpret_cast<volatile int*>(&xch[slot][w][3]) = i;
+        }
+      }
       // LDS-only barrier: a __syncthreads() would also wait (vmcnt(0)) for this row's global stores to be acknowledged
-      if (sync) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (sync && !flags) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (w > 0) {
         int fk = NEGK;                                      // prefix over columns 1 .. W0-1
         int d0 = P_MATCH; uint32_t p0 = kNullPtr;
 #pragma unroll
         for (int v = 0; v < NW - 1; ++v) {
           if (v < w) {                                      // wave-uniform; one ds_read_b128 per earlier wave
-            const int4 t = sync ? *reinterpret_cast<const int4*>(&xch[slot][v][0]) : xin[v];
+            int4 t;
+            if (flags) {
+              for (int spin = 0; spin < (1 << 24) && __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(&xch[slot][v][3])) != i; ++spin) {}
+              asm volatile("" ::: "memory");                // the record is read after its tag was seen
+              t = *reinterpret_cast<const int4*>(&xch[slot][v][0]);
+            } else t = sync ? *reinterpret_cast<const int4*>(&xch[slot][v][0]) : xin[v];
             fk = max(fk, t.x);
             if (v < w - 1) {
               const int Cn = (v + 1) * GW * R;
@@ -259,6 +287,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
         }
       }
     }
+    if (NW > 1 && sync && !SEGQ && prm.flag_sync && w > 0 && lane == 0) *reinterpret_cast<volatile int*>(&prog[w]) = i;   // records of row i are read
     if (LOCAL) {
       int rm = P_MATCH;
 #pragma unroll
@@ -637,6 +666,7 @@ int launch_dp_affine_tag(aln_batch* b) {
   // on one stream (the arbiter's favouritism costs ~6 %) and loses when the caller overlaps launches of several contexts
   prm.alt_prio = b->ctx->hints.tag_alt_prio;
   prm.early_store = b->ctx->hints.tag_early_store;
+  prm.flag_sync = b->ctx->hints.tag_flag_sync;
   prm.lag = b->ctx->hints.tag_lag;
   if (prm.lag < 0 || prm.lag > 4 || (prm.lag & (prm.lag - 1))) prm.lag = 0;      // 0, 1, 2 or 4: lag * (NW-1) + lag <= 16 slots for NW <= 4
   const int ld = b->maxld;
