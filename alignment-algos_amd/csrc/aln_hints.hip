@@ -24,8 +24,6 @@ const HintDef kDefs[] = {
     {"key16", "ALN_NO_KEY16", true, &aln_hints::key16},
     {"tag_alt_prio", "ALN_TAG_ALT_PRIO", false, &aln_hints::tag_alt_prio},
     {"tag_lag", "ALN_TAG_LAG", false, &aln_hints::tag_lag},
-    {"tag_flag_sync", "ALN_TAG_FLAG_SYNC", false, &aln_hints::tag_flag_sync},
-    {"tag_early_store", "ALN_TAG_EARLY_STORE", false, &aln_hints::tag_early_store},
     {"tag_segments", "ALN_TAG_SEGMENTS", false, &aln_hints::tag_segments},
     {"tag_solo", "ALN_TAG_SOLO", false, &aln_hints::tag_solo},
     {"tag_bits", "ALN_TAG_BITS", false, &aln_hints::tag_bits},

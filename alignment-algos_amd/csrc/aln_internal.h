@@ -61,8 +61,6 @@ struct aln_hints {
   int key16 = 1;             // 0: never use the 16-bit key layout
   int tag_alt_prio = 1;      // tagged kernel: alternate s_setprio per row by hardware-slot parity (pays on lone launches; a caller that
                              // overlaps launches of several contexts sets 0)
-  int tag_flag_sync = 0;     // tagged kernel: 1 = row records travel through polled, row-tagged LDS slots instead of a barrier per row
-  int tag_early_store = 0;   // tagged kernel: 1 = store a row's later column groups before its scans and exchange (see dp_affine_tag.hip)
   int tag_lag = 0;           // tagged kernel: rows wave w runs behind wave w-1 (skewed exchange, one barrier every tag_lag rows); 0 = the
                              // synchronous per-row exchange.  Measured on MI355X (config 2, lone launches): lag 0 3.11 ms, 1: 3.20, 2: 3.10,
                              // 4: 3.28; four overlapping streams 2.82 vs 3.38 — the waves of a pair drifting apart costs more in HBM

@@ -62,7 +62,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
   constexpr int RING = 16;              // exchange slots: one per row, reused every 16 rows
   __shared__ __attribute__((aligned(16))) int xch[RING][NW][4];
   __shared__ int red[NW][2];
-  __shared__ int prog[NW];              // flag exchange: the last row each wave has finished reading its neighbours' records for
 
   // ---- which pair, which rows ------------------------------------------------------------------------------------
   __shared__ int s_item;
@@ -109,8 +108,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
 
   for (int k = threadIdx.x; k < 32 * 32; k += 64 * NW) tab[k] = table32[k] * (1 << KB);
   for (int k = threadIdx.x; k < Q; k += 64 * NW) qcs[k] = qc[k];
-  if (threadIdx.x < NW) prog[threadIdx.x] = 0;
-  if (threadIdx.x < RING * NW) xch[threadIdx.x / NW][threadIdx.x % NW][3] = -1;      // row tags: no record yet
   __syncthreads();
 
   // ---- static per-column constants -----------------------------------------------------------------
@@ -171,16 +168,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
     if constexpr (X == 4) { const u32x2 v = {wd[0], wd[1]}; __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, 0); }
     else { const u32x4 v = {wd[0], wd[1], wd[2], wd[3]}; __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0); }
   };
-  // groups [r0, r1) of row i.  finish_row stores the groups whose cells are final (all but group 0, whose first cell of wave w > 0
-  // arrives with the exchange) BEFORE its scans and its barrier and group 0 after them (hint tag_early_store): the row's stores
-  // reach the memory pipeline in two bursts half a row apart instead of one
-  auto store_groups = [&](int i, int r0, int r1) {
+  auto store_row = [&](int i) {
     const size_t ro = (size_t)i * ld + cb;
     const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(P + (size_t)i * ld, 0, ld * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(H16p + (size_t)i * ld, 0, ld * 2, 0x00020000);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      if (r < r0 || r >= r1) continue;
       // low halves of two pointer words (at KB = 16: of two whole keys): one v_perm_b32 per pair of cells
       uint32_t pw[X / 2], hw[X / 2];
 #pragma unroll
@@ -202,7 +195,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
       store_words(pw, rsP, vo16 + 2 * GW * r);
     }
   };
-  auto store_row = [&](int i) { store_groups(i, 0, R); };
   auto tab_at = [&](int qrow, int c4) -> int {
     return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(tab) + qrow + c4);
   };
@@ -210,8 +202,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
   // Finish the row held in dk[]/pf[] (complete except, for w > 0, the wave's first column which the previous wave
   // computed and passes as (dB,pB)): prefix-scan preparation for the next row, exchange, local-max tracking, store.
   auto finish_row = [&](int i, int dB, uint32_t pB, bool sync, const int4 (&xin)[NW > 1 ? NW - 1 : 1]) {
-    const bool early = R > 1 && prm.early_store;
-    if (early) store_groups(i, 1, R);
     int sk = NEGK;     // scalar carry: prefix key over this wave's earlier groups
     int ik[R];
 #pragma unroll
@@ -233,41 +223,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
     }
     if (NW > 1) {
       const int slot = i & (RING - 1);
-      // Flag exchange (hint tag_flag_sync, synchronous mode only): the dependence runs one way — wave w needs the records of the
-      // waves before it, nobody needs anything from the waves after — so no wave has to wait at a barrier for a LATER one.  A
-      // record carries its row number in its fourth word (one 16-byte LDS write): a consumer polls until the tag is its row.
-      // The ring has 16 slots: every 8 rows a producer makes sure the later waves have read up to 8 rows back before it goes on.
-      const bool flags = sync && !SEGQ && prm.flag_sync;
-      if (flags && w < NW - 1 && (i & 7) == 0 && i >= 16) {
-#pragma unroll
-        for (int v = 1; v < NW; ++v) {
-          if (v > w) {                                      // (bounded: a broken exchange must end in wrong planes the tests catch, never in a hang)
-            for (int spin = 0; spin < (1 << 24) && __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(&prog[v])) < i - 8; ++spin)
-              __builtin_amdgcn_s_sleep(0);
-          }
-        }
-      }
-      if (lane == 63) {
-        xch[slot][w][0] = sk; xch[slot][w][1] = dB; xch[slot][w][2] = (int)pB;
-        if (flags) {                                        // the tag goes last (a wave's LDS operations are served in order)
-          asm volatile("" ::: "memory");
-          *reinterpret_cast<volatile int*>(&xch[slot][w][3]) = i;
-        }
-      }
+      if (lane == 63) { xch[slot][w][0] = sk; xch[slot][w][1] = dB; xch[slot][w][2] = (int)pB; }
       // LDS-only barrier: a __syncthreads() would also wait (vmcnt(0)) for this row's global stores to be acknowledged
-      if (sync && !flags) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (sync) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (w > 0) {
         int fk = NEGK;                                      // prefix over columns 1 .. W0-1
         int d0 = P_MATCH; uint32_t p0 = kNullPtr;
 #pragma unroll
         for (int v = 0; v < NW - 1; ++v) {
           if (v < w) {                                      // wave-uniform; one ds_read_b128 per earlier wave
-            int4 t;
-            if (flags) {
-              for (int spin = 0; spin < (1 << 24) && __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(&xch[slot][v][3])) != i; ++spin) {}
-              asm volatile("" ::: "memory");                // the record is read after its tag was seen
-              t = *reinterpret_cast<const int4*>(&xch[slot][v][0]);
-            } else t = sync ? *reinterpret_cast<const int4*>(&xch[slot][v][0]) : xin[v];
+            const int4 t = sync ? *reinterpret_cast<const int4*>(&xch[slot][v][0]) : xin[v];
             fk = max(fk, t.x);
             if (v < w - 1) {
               const int Cn = (v + 1) * GW * R;
@@ -287,7 +252,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
         }
       }
     }
-    if (NW > 1 && sync && !SEGQ && prm.flag_sync && w > 0 && lane == 0) *reinterpret_cast<volatile int*>(&prog[w]) = i;   // records of row i are read
     if (LOCAL) {
       int rm = P_MATCH;
 #pragma unroll
@@ -304,7 +268,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(R * X =
         lpos = ((uint32_t)i << 16) | (uint32_t)cfirst;
       }
     }
-    if (early) store_groups(i, 0, 1); else store_row(i);
+    store_row(i);
   };
 
   // ---- hand-off slots of the segment queue: 9 x 16 bytes per thread (dk[16], gmx[16], cvk[R], lmax, lpos), chunk-major ------
@@ -665,8 +629,6 @@ int launch_dp_affine_tag(aln_batch* b) {
   // row-alternating wave priority: a per-context hint (aln_ctx_set_hint "tag_alt_prio"): it pays while launches follow each other
   // on one stream (the arbiter's favouritism costs ~6 %) and loses when the caller overlaps launches of several contexts
   prm.alt_prio = b->ctx->hints.tag_alt_prio;
-  prm.early_store = b->ctx->hints.tag_early_store;
-  prm.flag_sync = b->ctx->hints.tag_flag_sync;
   prm.lag = b->ctx->hints.tag_lag;
   if (prm.lag < 0 || prm.lag > 4 || (prm.lag & (prm.lag - 1))) prm.lag = 0;      // 0, 1, 2 or 4: lag * (NW-1) + lag <= 16 slots for NW <= 4
   const int ld = b->maxld;

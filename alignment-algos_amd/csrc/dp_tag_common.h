@@ -23,8 +23,6 @@ struct TagParams {
   int gi, ge;
   int free_del, free_ins;
   int alt_prio;
-  int flag_sync;     // 1: the waves of a pair exchange their row records through tagged LDS slots that the consumer polls; no per-row barrier
-  int early_store;   // 1: a row's groups other than the first are stored before the row's scans and exchange (two store bursts per row)
   int lag;        // 0: the waves of a pair exchange their row state synchronously (write, barrier, read inside every row);
                   // L = 2^k >= 1: wave w runs L*w rows behind wave 0 and reads what the earlier waves left in a ring of
                   // exchange slots, one workgroup barrier every L rows (see "skewed exchange" below)
