@@ -35,6 +35,7 @@ const HintDef kDefs[] = {
     {"exact_literal", "ALN_EXACT_LITERAL", false, &aln_hints::exact_literal},
     {"exact_alt_prio", "ALN_EXACT_ALT_PRIO", false, &aln_hints::exact_alt_prio},
     {"exact_prune", "ALN_EXACT_PRUNE", false, &aln_hints::exact_prune},
+    {"exact_wavefront", "ALN_EXACT_WAVEFRONT", false, &aln_hints::exact_wavefront},
     {"exact_debug", "ALN_EXACT_DEBUG", false, &aln_hints::exact_debug},
     {"score_packed", "ALN_SCORE_NO_PACKED", true, &aln_hints::score_packed},
     {"enum_heavy_first", "ALN_ENUM_HEAVY_FIRST", false, &aln_hints::enum_heavy_first},

@@ -74,9 +74,11 @@ struct aln_hints {
   int dp_nw = 0, dp_r = 0, dp_x = 0;   // force a row-sweep variant (waves per pair, groups per lane, columns per lane and group); 0 = auto
   int exact_tiles = 1;       // 0: dp_exact_blocked instead of dp_exact_tiled where both apply
   int exact_literal = 0;     // 1: the literal O(n^3) kernel everywhere
-  int exact_alt_prio = 1;    // tiled exact kernel: priority rotation over the 4 resident waves
+  int exact_alt_prio = 2;    // tiled exact kernel: 1 = priority rotation over the 4 resident waves, 2 = priority by progress (waves ahead of the launch's average yield), 0 = none
+  int exact_wavefront = 1;   // tiled exact kernel: 64-column tiles, the four waves of a pair on four row blocks (one barrier per tile); 0: 256-column tiles, one barrier per row
   int exact_prune = 1;       // tiled exact kernel: skip far chunks that provably cannot matter (bit-exact; dp_exact_blocked.hip)
-  int exact_debug = 0;       // 1: the tiled kernel counts tested / skipped far chunks (aln_batch_last_exact_stats)
+  int exact_debug = 0;       // 1: the tiled kernel counts tested / skipped far chunks (aln_batch_last_exact_stats); 2: the same four words hold
+                             // how long its waves ran (sum, longest, ~shortest, count; units of 1024 s_memtime ticks)
   int score_packed = 1;      // 0: one query per wave in aln_score_all_vs_all
   int plane_row_align = 8;   // cells a plane row is padded to when a batch is created (8, 16, 32 or 64)
   int64_t enum_node_cap = 0; // trie nodes of aln_batch_enumerate (0 = default)

@@ -465,6 +465,19 @@ __global__ __launch_bounds__(kBT, 2) void dp_exact_blocked_kernel(const PairDesc
 // The remaining candidates k in [b0-1, b-2] (inside the tile, <= 255) are scanned per row from LDS exactly like
 // dp_exact_blocked does, starting from the far-left (max, e, chunk) state, so the "first k" bookkeeping is unchanged.
 // Far insertions: the 16-row sliding window of dp_exact_blocked, per tile.
+//
+// Two forms of the schedule (template parameter WF; hint exact_wavefront, default on):
+//   256-column tiles: the four waves share a tile, a row of it needs the previous row of ALL of it -> one workgroup barrier per
+//     row (18 k per 2000 x 2000 pair), the wave that owns the tile's last 64 columns scans 256 in-tile candidates per cell and the
+//     first 64, and the others wait for it;
+//   wavefront (round 3): 64-column tiles, wave w owns the row blocks w, w+4, ... and sweeps each left to right one tile behind
+//     the wave that owns the block above.  A tile's own candidates are the wave's own previous rows (kept in LDS, which also
+//     serves the near insertions), so nothing is shared inside a tile: no workgroup barrier at all — a wave publishes its tile
+//     count in LDS once its stores have reached L2, its follower polls that word — every wave does the same work, and the
+//     in-tile scan is 64 candidates per cell for all of them (18 % fewer VALU instructions on config 3).  A lone 700 x 700 batch
+//     of 8 pairs: 36.8 -> 23.3 ms; 1024 pairs of 2000 x 2000: 408 -> 397 ms (the far scans' memory round trips bound that one).
+// Pointers: the scans leave (chunk, tie flag) per cell; which k of the chunk it was is found by the WAVE — the 32 (16)
+// candidates of a cell are evaluated by as many lanes at once, two (four) cells per round — not by each lane walking alone.
 typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2v sload2(const float* p) {
   f2v v;
@@ -529,6 +542,10 @@ __device__ __forceinline__ float vmin_sv(float s, float v) { float r; asm("v_min
 
 constexpr int kTW = 256;       // tile width = threads
 constexpr int kTRing = 32;     // frame-ordered copies of finished rows kept per workgroup (>= kBR + 1)
+constexpr int kWRing = 128;    // wavefront form: four row blocks are in flight (+ the row above the oldest)
+constexpr int kWT = 64;        // wavefront form: tile width = one wave
+constexpr int kWRow = 68;       // wavefront form: a wave's LDS copy of one row of its tile (column kbase + its 64 columns, padded to 16 bytes)
+constexpr int kWHist = (kBR + 1) * kWRow;   // ... rows a0-1 .. a0+15: the sources of the tile's own deletion scans AND of its near insertions
 constexpr int kTLoc = 320;     // tile-local row buffer: 257 live entries + pads the masked tail may read
 
 // GM = gap model: 0 constant affine (aasubalib.h:27-77), 1 min(t1,t2) position coefficients (hmap2_eval.h:41-95), 2 Gn2Eval's
@@ -537,7 +554,7 @@ constexpr int kTLoc = 320;     // tile-local row buffer: 257 live entries + pads
 // (gi[t1] + ge[t1] * (dist - 2)) + cn[t1] with the coefficients of the SMALLER template position alone.
 // `delF`: GM 2 only; entry [k * pitch + b] of pair p's table at delF_off[p] is the deletion between FRAME columns k < b
 // (forward builds: the caller's table; reverse builds: its flipped transpose, see launch_dp_exact_blocked).
-template <int PT, int GM, bool LOCAL>
+template <int PT, int GM, bool LOCAL, bool WF>
 __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* __restrict__ pairs, EvalDev proto,
                                                                  const uint8_t* __restrict__ qcodes, const uint8_t* __restrict__ tcodes,
                                                                  const float* __restrict__ tgi, const float* __restrict__ tge,
@@ -546,16 +563,20 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
                                                                  float* __restrict__ scratch_base, int alt_prio,
                                                                  const float* __restrict__ delF_base, const int64_t* __restrict__ delF_off,
                                                                  int prune, int q_blocks, const float* __restrict__ smax_arr, float smax_const,
-                                                                 unsigned long long* __restrict__ dbg) {
+                                                                 unsigned long long* __restrict__ dbg, unsigned int* __restrict__ gprog) {
   constexpr bool TPOS = GM == 1;
   constexpr bool TAB = GM == 2;
+  constexpr int RING = WF ? kWRing : kTRing;            // finished rows kept per workgroup
+  constexpr int TWv = WF ? kWT : kTW;                   // tile width
   __shared__ float2 cminl[PT / 32 + 1];                 // per 32-column chunk: the smallest (tgi, tge) in it (frame order)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float2* tg = reinterpret_cast<float2*>(lds);          // (tgi, tge) in frame order, PT entries
   float* rowloc0 = lds + 2 * PT;                         // rows a-1 / a of the current tile, index k - kbase
   float* rowloc1 = rowloc0 + kTLoc;
-  float* tcnl = rowloc1 + kTLoc;                         // GM 2: Gn2Eval's v_cn in frame order, PT entries
+  float* tcnl = rowloc0 + (WF ? 4 * kWHist : 2 * kTLoc);                         // GM 2: Gn2Eval's v_cn in frame order, PT entries
   __shared__ float red_v[kTW / 64];
+  __shared__ int wdone[kTW / 64];                       // WF: tiles finished by each wave
+  __shared__ float edgeL[kTW / 64][32];                 // WF: column kbase (the previous tile's last) of rows a0-1 .. a0+15, per wave
   __shared__ uint32_t red_p[kTW / 64];
   const float ninf = -__builtin_inff();
 
@@ -573,7 +594,8 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
   const int ld = pd.ld;
   const Frame f = {pd.q0, pd.q1, pd.t0, pd.t1, rev};
   const int nQ = f.nQ(), nT = f.nT();
-  const int tid = threadIdx.x, wave = tid >> 6;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: what the wavefront form derives from it (row block, tile) stays in SGPRs
+  const int lt = WF ? (tid & 63) : tid;                  // thread's place in its tile
   const float gi_c = e.gi, ge_c = e.ge;
   // GM 2: the frame-ordered deletion table of this pair, pitch = the template's real length; frame column 0 = real t0 (forward)
   // or t1 (reverse, in the flipped table: index T-1-t1)
@@ -583,21 +605,26 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
   auto del_at = [&](int k, int b) -> float { return delF[(size_t)(k < TT ? k : TT - 1) * TT + b]; };   // k clamped: masked candidates only
   // per-workgroup scratch: far-insertion and far-left-deletion results [2][3][kBR][PT] (own words only, read back through L2),
   // finished rows in frame order [kTRing][PT], (tgi, tge) [2][PT]
-  float* scr_m = scratch_base + (size_t)blockIdx.x * (size_t)(6 * kBR + kTRing + 3 + q_blocks) * PT;
-  float* scr_e = scr_m + kBR * PT;
-  int* scr_c = reinterpret_cast<int*>(scr_e + kBR * PT);
-  float* fdm = scr_m + 3 * kBR * PT;
-  float* fde = fdm + kBR * PT;
-  int* fdc = reinterpret_cast<int*>(fde + kBR * PT);
-  float* rowsF = scr_m + 6 * kBR * PT;
-  float* tgiF = rowsF + kTRing * PT;
+  float* const scr0 = scratch_base + (size_t)blockIdx.x * (size_t)(6 * kBR + RING + 2 + RING / 32 + q_blocks) * PT;
+  // far-scan results (m, e, chunk) x (insertions, deletions), [kBR][SP] each.  WF: a wave keeps its own six planes for the tile it
+  // is working on (64 columns; the waves are not in lockstep, so two of them may be at the same columns of different row blocks)
+  constexpr int SP = WF ? kWT : PT;
+  float* scr_m = WF ? scr0 + (size_t)wave * (6 * kBR * kWT) : scr0;
+  float* scr_e = scr_m + kBR * SP;
+  int* scr_c = reinterpret_cast<int*>(scr_e + kBR * SP);
+  float* fdm = scr_m + 3 * kBR * SP;
+  float* fde = fdm + kBR * SP;
+  int* fdc = reinterpret_cast<int*>(fde + kBR * SP);
+  float* rowsF = scr0 + 6 * kBR * PT;
+  float* tgiF = rowsF + RING * PT;
   float* tgeF = tgiF + PT;
   float* delmaxF = tgeF + PT;                            // [PT/32 chunks][kTRing row slots]: chunk maxima of finished rows
-  float* insmaxF = delmaxF + PT;                         // [q_blocks][PT]: column maxima of finished 16-row blocks
+  float* insmaxF = delmaxF + (RING / 32) * PT;                         // [q_blocks][PT]: column maxima of finished 16-row blocks
   const float ceps = ((smax_arr ? smax_arr[blockIdx.x] : smax_const) + 1.0f) * kPruneEps;
   const bool prune_del = (prune & 1) && !TAB;            // a tabulated deletion has no monotone lower bound
   const bool prune_ins = (prune & 2) != 0;
   unsigned n_tested_d = 0, n_skip_d = 0, n_tested_i = 0, n_skip_i = 0;
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 
   float lmax = 0.f; uint32_t lpos = 0xFFFFFFFFu;
   const uint32_t origin = pack_ptr(f.rq(0), f.rt(0));
@@ -610,7 +637,8 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
       tgiF[x] = v.x; tgeF[x] = v.y;
       if (TAB) tcnl[x] = (x <= nT) ? e.tcn[f.rt(x)] : 0.f;
     }
-    for (int x = tid; x < 2 * kTLoc; x += kTW) rowloc0[x] = ninf;
+    for (int x = tid; x < (WF ? 4 * kWHist : 2 * kTLoc); x += kTW) rowloc0[x] = ninf;
+    if (tid < kTW / 64) wdone[tid] = 0;
     __threadfence_block();
     __syncthreads();
     for (int c = tid; c < PT / 32; c += kTW) {
@@ -620,15 +648,29 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
       cminl[c] = mn;
     }
     __syncthreads();
-    const int ntiles = (nT - 1 + kTW - 1) / kTW;
+    const int ntiles = (nT - 1 + TWv - 1) / TWv;
+    float* const rlw = rowloc0 + wave * kWHist;           // WF: this wave's rows of the current tile
 
     const int hwslot = (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_ID.WAVE_ID
-    for (int a0 = 1; a0 <= nQ - 1; a0 += kBR) {
-      const int a_end = (a0 + kBR - 1 < nQ - 1) ? a0 + kBR - 1 : nQ - 1;
-      // The SIMD arbiter favours its oldest wave, so of the 4 pairs resident on a CU the first would run ahead and the last
-      // finish alone on a half-empty SIMD (measured on the tagged kernel).  Rotating the user priority over
-      // the 4 wave slots of a SIMD, one step per row block, keeps the pairs abreast: 854 -> 771 ms on config 3.
-      if (alt_prio) {
+    // The SIMD arbiter favours its oldest wave, so of the 4 pairs resident on a CU the first would run ahead and the last
+    // finish alone on a half-empty SIMD (measured on the tagged kernel).  Rotating the user priority over
+    // the 4 wave slots of a SIMD, one step per row block, keeps the pairs abreast: 854 -> 771 ms on config 3.
+    // alt_prio 2: by PROGRESS.  Measured (exact_debug 2): with 1024 pairs of one size the average wave is done after 0.6 of the
+    // launch — the arbiter's favourites run ahead, finish, and leave the rest to run with fewer waves per SIMD, which is slower
+    // for everyone left.  Every wave counts its row blocks in one device word as it starts them; what it gets back is how far
+    // the launch is on average, and a wave ahead of that lowers its priority, a wave behind raises it.
+    auto set_prio = [&](int a0) {
+      if (alt_prio == 2) {
+        unsigned tot = 0;
+        if ((tid & 63) == 0) tot = __hip_atomic_fetch_add(gprog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tot = __builtin_amdgcn_readfirstlane(tot);
+        const int mine = WF ? (a0 - 1) / (4 * kBR) : (a0 - 1) / kBR;       // blocks this wave has started before this one
+        const int lead = mine - (int)(tot / (4u * gridDim.x));
+        if (lead >= 2) __builtin_amdgcn_s_setprio(0);
+        else if (lead == 1) __builtin_amdgcn_s_setprio(1);
+        else if (lead == 0) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+      } else if (alt_prio) {
         switch (((a0 / kBR) + hwslot) & 3) {
           case 0: __builtin_amdgcn_s_setprio(0); break;
           case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -636,11 +678,16 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
           default: __builtin_amdgcn_s_setprio(3); break;
         }
       }
-      for (int cb = 0; cb < ntiles; ++cb) {
-        const int kbase = kTW * cb;                    // = b0 - 1: first near source column of the tile
-        const int bc = kbase + 1 + tid;                // this thread's column
+    };
+    // one tile: rows a0 .. a0+15 x columns TWv * cb + 1 .. TWv * cb + TWv
+    auto do_tile = [&](const int a0, const int cb) __attribute__((always_inline)) {
+      const int a_end = (a0 + kBR - 1 < nQ - 1) ? a0 + kBR - 1 : nQ - 1;
+      {
+        const int kbase = TWv * cb;                    // = b0 - 1: first near source column of the tile
+        const int bc = kbase + 1 + lt;                // this thread's column
+        const int sc = WF ? lt : bc;                   // ... and its place in the far-scan result planes
         const bool bv = bc <= nT - 1;
-        const bool wave_on = kbase + 1 + 64 * wave <= nT - 1;
+        const bool wave_on = WF ? true : kbase + 1 + 64 * wave <= nT - 1;
         float colmax = ninf;                           // this column's maximum over the rows of the block (tile epilogue)
         // ============ far insertions of rows a0 .. a0+15 for column bc: candidates k = 1 .. a0-2 =====================
         // Source rows in chunks of 16 that coincide with the row blocks (rows 16j+1 .. 16j+16), nearest chunk first; (m, e, c)
@@ -698,6 +745,10 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
             // the others in groups of 8, nearest group first: the group's 8 column maxima are loaded together (one memory
             // latency per group instead of one per chunk), every chunk is tested against the state BEFORE the group (m only
             // grows, so a chunk that may be skipped now may be skipped later), the chunks that fail are scanned nearest first
+            // (the NEXT group's maxima are requested before this group's chunks are scanned)
+            float cnext[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) cnext[t] = (prune_ins && jtop - 1 - t >= 0) ? aload(cmaxcol + (size_t)(jtop - 1 - t) * PT) : ninf;
 #pragma unroll 1
             for (int jg = jtop - 1; jg >= 0; jg -= 8) {
               const int ng = jg + 1 < 8 ? jg + 1 : 8;
@@ -705,7 +756,7 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
               if (prune_ins) {
                 float cmxv[8], thr[HW];
 #pragma unroll
-                for (int t = 0; t < 8; ++t) cmxv[t] = (t < ng) ? aload(cmaxcol + (size_t)(jg - t) * PT) : ninf;
+                for (int t = 0; t < 8; ++t) { cmxv[t] = cnext[t]; cnext[t] = (jg - 8 - t >= 0) ? aload(cmaxcol + (size_t)(jg - 8 - t) * PT) : ninf; }
 #pragma unroll
                 for (int i = 0; i < HW; ++i) thr[i] = (a0 + HW * h + i > a_end) ? __builtin_inff() : prune_thr(m[i], ceps);
                 todo = 0u;
@@ -735,14 +786,13 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
             if (bv && bc >= 2) {
 #pragma unroll
               for (int r = 0; r < HW; ++r) {
-                scr_m[(HW * h + r) * PT + bc] = m[r]; scr_e[(HW * h + r) * PT + bc] = ee[r]; scr_c[(HW * h + r) * PT + bc] = cc[r];
+                scr_m[(HW * h + r) * SP + sc] = m[r]; scr_e[(HW * h + r) * SP + sc] = ee[r]; scr_c[(HW * h + r) * SP + sc] = cc[r];
               }
             }
           }
         }
         // ============ far-left deletions: sources k = 1 .. kbase-1 of rows a0-1 .. a0+14, shared gap values ===========
-        // 32-column chunks, nearest first, same (m, e, c) convention and skip rule as the far insertions; the 16 rows' maxima of
-        // a chunk are one s_load_dwordx16.
+        // 32-column chunks, nearest first, same (m, e, c) convention and skip rule as the far insertions.
         if (cb >= 1 && a_end >= 2 && wave_on) {
           __builtin_amdgcn_s_dcache_inv();             // the source rows were written through the vector path
           const int b = bv ? bc : kbase + 1;
@@ -752,94 +802,141 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
 #pragma unroll
           for (int r = 0; r < kBR; ++r) { m[r] = ninf; ee[r] = ninf; cc[r] = 0; }
           // source row of target row a0+r is a0+r-1: ring slots (a0-1) & 31 + r — consecutive, because a0-1 is a multiple of 16
-          const int slot0 = (a0 - 1) & (kTRing - 1);
+          const int slot0 = (a0 - 1) & (RING - 1);
           const float* sbase = rowsF + (size_t)slot0 * PT;
           const float* mbase = delmaxF + slot0;
           const int r_lo = (a0 == 1) ? 1 : 0, r_hi = a_end - a0;      // target rows whose far-left state is used
           const int ctop = kbase / kBC - 1;
-          // 4 source columns x 16 rows per trip: 18 scalar loads, one wait, 148 VALU instructions.  (Double-buffering the
-          // SGPRs was tried: under the kernel's SGPR pressure the compiler copies the in-flight registers and waits early.)
+          // Skip tests, four chunks at a time: lane l holds the maximum of row (l & 15) of chunk gbase - (l >> 4) — one vector load
+          // per group, the NEXT group's already in flight while this one is tested and scanned (a scalar load per chunk was one
+          // dependent round trip per test) — and a row's bound reaches the lanes as a v_readlane operand.  A group is tested against
+          // the state before it (m only grows: what may be skipped now may be skipped later).
+          const int ln = tid & 63;
+          const float* mlane = mbase + (ln & 15);
+          const int lq = ln >> 4;
+          auto gload = [&](int gb) { int ch = gb - lq; ch = ch < 0 ? 0 : ch; return aload(mlane + (size_t)ch * RING); };
+          int gbase = ctop;
+          unsigned todo = 1u;                            // bit t = chunk gbase - t; the nearest chunk: always
+          float nxt = (prune_del && ctop >= 1) ? gload(ctop - 1) : 0.f;
 #pragma unroll 1
-          for (int c = ctop; c >= 0; --c) {
-            const int kc = c * kBC;
-            if (prune_del && c != ctop) {
-              const f16v mx = sload16(mbase + (size_t)c * kTRing);
-              const float2 cmn = cminl[c];
-              const float dist = (float)(b - (kc + kBC - 1) - 2);
-              const float g_lb = (TPOS ? fminr(cmn.x, gib) : gi_c) + (TPOS ? fminr(cmn.y, geb) : ge_c) * dist;
-              bool ok = true;
+          for (;;) {
+            // 4 source columns x 16 rows per trip: 18 scalar loads, one wait, 148 VALU instructions.  (Double-buffering the
+            // SGPRs was tried: under the kernel's SGPR pressure the compiler copies the in-flight registers and waits early.)
+#pragma unroll 1
+            while (todo) {
+              const int c = gbase - __builtin_ctz(todo);
+              todo &= todo - 1u;
+              const int kc = c * kBC;
+              float fd = (float)(b - 2 - kc);
+#pragma unroll
+              for (int r = 0; r < kBR; ++r) cm[r] = ninf;
+#pragma unroll 1
+              for (int k = kc; k < kc + kBC; k += 4) {
+                f4v src[kBR];
+                sload_rows<0, kBR, PT>(src, sbase + k);
+                f4v gk = {0.f, 0.f, 0.f, 0.f}, ek = {0.f, 0.f, 0.f, 0.f};
+                if (TPOS) { gk = sload4_imm<0>(tgiF + k); ek = sload4_imm<PT * 4>(tgiF + k); }
+                float gt[4] = {0.f, 0.f, 0.f, 0.f};
+                if (TAB) {
+#pragma unroll
+                  for (int u = 0; u < 4; ++u) gt[u] = delF[(size_t)(k + u) * TT + b];      // k + u < kbase <= b - 1: inside the table
+                }
+                swait_lgkm0();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  const float gi = TPOS ? vmin_sv(gk[u], gib) : gi_c;
+                  const float ge = TPOS ? vmin_sv(ek[u], geb) : ge_c;
+                  const float g = TAB ? gt[u] : gi + ge * fd;
+                  fd -= 1.0f;
+                  if (k + u == 0) continue;              // column 0 is never a source (dpmatrix.h:459 starts at t0+1)
+#pragma unroll
+                  for (int r = 0; r < kBR; r += 4)
+                    submax4_sv(cm[r], cm[r + 1], cm[r + 2], cm[r + 3], src[r][u], src[r + 1][u], src[r + 2][u], src[r + 3][u], g);
+                }
+              }
 #pragma unroll
               for (int r = 0; r < kBR; ++r) {
-                const float ub = mx[r] - g_lb;
-                ok = ok && ((ub < prune_thr(m[r], ceps)) || r < r_lo || r > r_hi);
-              }
-              ++n_tested_d;
-              if (__ballot(ok || !bv) == ~0ull) { ++n_skip_d; continue; }
-            }
-            float fd = (float)(b - 2 - kc);
-#pragma unroll
-            for (int r = 0; r < kBR; ++r) cm[r] = ninf;
-#pragma unroll 1
-            for (int k = kc; k < kc + kBC; k += 4) {
-              f4v src[kBR];
-              sload_rows<0, kBR, PT>(src, sbase + k);
-              f4v gk = {0.f, 0.f, 0.f, 0.f}, ek = {0.f, 0.f, 0.f, 0.f};
-              if (TPOS) { gk = sload4_imm<0>(tgiF + k); ek = sload4_imm<PT * 4>(tgiF + k); }
-              float gt[4] = {0.f, 0.f, 0.f, 0.f};
-              if (TAB) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) gt[u] = delF[(size_t)(k + u) * TT + b];      // k + u < kbase <= b - 1: inside the table
-              }
-              swait_lgkm0();
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                const float gi = TPOS ? vmin_sv(gk[u], gib) : gi_c;
-                const float ge = TPOS ? vmin_sv(ek[u], geb) : ge_c;
-                const float g = TAB ? gt[u] : gi + ge * fd;
-                fd -= 1.0f;
-                if (k + u == 0) continue;              // column 0 is never a source (dpmatrix.h:459 starts at t0+1)
-#pragma unroll
-                for (int r = 0; r < kBR; r += 4)
-                  submax4_sv(cm[r], cm[r + 1], cm[r + 2], cm[r + 3], src[r][u], src[r + 1][u], src[r + 2][u], src[r + 3][u], g);
+                const bool up = cm[r] >= m[r];
+                ee[r] = up ? ninf : vmaxf(ee[r], cm[r]);
+                cc[r] = up ? kc : cc[r];
+                m[r] = up ? cm[r] : m[r];
               }
             }
+            gbase -= (gbase == ctop) ? 1 : 4;
+            if (gbase < 0) break;
+            const int ng = gbase + 1 < 4 ? gbase + 1 : 4;
+            todo = (1u << ng) - 1u;
+            if (prune_del) {
+              const float curv = nxt;
+              if (gbase >= 4) nxt = gload(gbase - 4);
+              float thr[kBR];
 #pragma unroll
-            for (int r = 0; r < kBR; ++r) {
-              const bool up = cm[r] >= m[r];
-              ee[r] = up ? ninf : vmaxf(ee[r], cm[r]);
-              cc[r] = up ? kc : cc[r];
-              m[r] = up ? cm[r] : m[r];
+              for (int r = 0; r < kBR; ++r) thr[r] = (r < r_lo || r > r_hi) ? __builtin_inff() : prune_thr(m[r], ceps);
+              todo = 0u;
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                if (t < ng) {
+                  const int c = gbase - t;
+                  const float2 cmn = cminl[c];
+                  const float dist = (float)(b - (c * kBC + kBC - 1) - 2);
+                  const float g_lb = (TPOS ? fminr(cmn.x, gib) : gi_c) + (TPOS ? fminr(cmn.y, geb) : ge_c) * dist;
+                  bool ok = true;
+#pragma unroll
+                  for (int r = 0; r < kBR; ++r) {
+                    const float mx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, curv), 16 * t + r));
+                    ok = ok && (mx - g_lb < thr[r]);
+                  }
+                  if (__ballot(ok || !bv) != ~0ull) todo |= 1u << t;
+                }
+              }
+              n_tested_d += (unsigned)ng;
+              n_skip_d += (unsigned)(ng - __builtin_popcount(todo));
             }
           }
 #pragma unroll
-          for (int r = 0; r < kBR; ++r) { fdm[r * PT + bc] = m[r]; fde[r * PT + bc] = ee[r]; fdc[r * PT + bc] = cc[r]; }
+          for (int r = 0; r < kBR; ++r) { fdm[r * SP + sc] = m[r]; fde[r * SP + sc] = ee[r]; fdc[r * SP + sc] = cc[r]; }
         }
         // ============ tile prologue: row a0-1 of the tile's columns (and column b0-1) into the local buffer ==========
         {
-          float* pv = ((a0 - 1) & 1) ? rowloc1 : rowloc0;
-          const float* src = rowsF + (size_t)((a0 - 1) & (kTRing - 1)) * PT;
+          float* pv = WF ? rlw : ((a0 - 1) & 1) ? rowloc1 : rowloc0;
+          const float* src = rowsF + (size_t)((a0 - 1) & (RING - 1)) * PT;
           float v = ninf;
           if (a0 >= 2 && bv) v = aload(&src[bc]);
-          pv[1 + tid] = v;
-          if (tid == 0) pv[0] = (a0 >= 2 && cb >= 1) ? aload(&src[kbase]) : ninf;
+          pv[1 + lt] = v;
+          if constexpr (WF) {
+            // column kbase of rows a0-1 .. a0+15 (rows of this block: written by this wave one step ago; row a0-1: by the wave
+            // that owns the block above, at least one step ago)
+            if (lt <= kBR) {
+              const int row = a0 - 1 + lt;
+              const float ev = (cb >= 1 && row >= 1 && row <= nQ - 1) ? aload(&rowsF[(size_t)(row & (RING - 1)) * PT + kbase]) : ninf;
+              edgeL[wave][lt] = ev;
+              if (lt == 0) pv[0] = ev;
+            }
+          } else {
+            if (tid == 0) pv[0] = (a0 >= 2 && cb >= 1) ? aload(&src[kbase]) : ninf;
+          }
         }
         __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
+        if constexpr (WF) { __threadfence_block(); __builtin_amdgcn_wave_barrier(); } else { __syncthreads(); }
 
         // ============ the rows of the block inside this tile ==========================================================
         for (int a = a0; a <= a_end; ++a) {
           const int i = f.rq(a);
           const int r = a - a0;
-          float* prevl = ((a - 1) & 1) ? rowloc1 : rowloc0;
-          float* curl = (a & 1) ? rowloc1 : rowloc0;
+          float* prevl = WF ? rlw + r * kWRow : ((a - 1) & 1) ? rowloc1 : rowloc0;
+          float* curl = WF ? rlw + (r + 1) * kWRow : (a & 1) ? rowloc1 : rowloc0;
           const float* prev = prevl - kbase;            // prev[k] for absolute k in [kbase, kbase + kTLoc)
-          float* rowF = rowsF + (size_t)(a & (kTRing - 1)) * PT;
+          float* rowF = rowsF + (size_t)(a & (RING - 1)) * PT;
           if (wave_on) {
             const bool valid = bv;
             const int bb = valid ? bc : 1;
+            const int sb = WF ? lt : bb;
             const int jj = f.rt(bb);
             const float sim = dev_sim(e, i, jj);
             float opt; uint32_t optp;
+            // what the pointer search below needs of a cell that a gap won (pcat 1: deletion, 2: far insertion)
+            int pcat = 0, pk = 0, oa = a - 1, ob = bb - 1; bool pamb = false, pgen = false;
+            float pgi = gi_c, pge = ge_c, pcn = 0.f;
             if (a == 1) {                                   // first row: dpmatrix.h:409-418
               float sv = 0.f;
               if (bb > 1) sv -= frame_del(e, f, 0, bb);
@@ -856,9 +953,9 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
               if (TPOS) { const float2 t = tg[bb]; s.gib[0] = t.x; s.geb[0] = t.y; } else { s.gib[0] = 0.f; s.geb[0] = 0.f; }
               s.fd[0] = (float)(bb - kbase - 2);
               s.cm[0] = ninf;
-              if (cb >= 1) { s.m[0] = aload(&fdm[r * PT + bb]); s.e[0] = aload(&fde[r * PT + bb]); s.cidx[0] = aloadi(&fdc[r * PT + bb]); }
+              if (cb >= 1) { s.m[0] = aload(&fdm[r * SP + sb]); s.e[0] = aload(&fde[r * SP + sb]); s.cidx[0] = aloadi(&fdc[r * SP + sb]); }
               else { s.m[0] = ninf; s.e[0] = ninf; s.cidx[0] = 0; }
-              const int tail = kbase + 64 * wave;
+              const int tail = WF ? kbase : kbase + 64 * wave;
               if constexpr (TAB) {
                 // the tile's own source columns: one table value per candidate, same 32-column chunks and (max, e, chunk) bookkeeping
                 for (int kc = kbase; kc < tail + 64; kc += kBC) {
@@ -885,9 +982,12 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
               const int kn0 = (a0 - 1 > 1) ? a0 - 1 : 1;
               float xn[kBR];
 #pragma unroll
-              for (int u = 0; u < kBR; ++u) xn[u] = (kn0 + u <= a - 2) ? aload(&H[(size_t)f.rq(kn0 + u) * ld + colb]) : ninf;
+              for (int u = 0; u < kBR; ++u) {
+                if constexpr (WF) xn[u] = (kn0 + u <= a - 2) ? rlw[(kn0 + u - (a0 - 1)) * kWRow + lt] : ninf;   // column b-1 = entry lt of the row's copy
+                else xn[u] = (kn0 + u <= a - 2) ? aload(&H[(size_t)f.rq(kn0 + u) * ld + colb]) : ninf;
+              }
               float mf = ninf, ef = ninf; int cf = 0;
-              if (a0 >= 3) { mf = aload(&scr_m[r * PT + bb]); ef = aload(&scr_e[r * PT + bb]); cf = aloadi(&scr_c[r * PT + bb]); }
+              if (a0 >= 3) { mf = aload(&scr_m[r * SP + sb]); ef = aload(&scr_e[r * SP + sb]); cf = aloadi(&scr_c[r * SP + sb]); }
               opt = clip0(prev[bb - 1] + sim, LOCAL);          // match, :447-451
               int cat = 0;
               const float sd = clip0(dm + sim, LOCAL);
@@ -910,12 +1010,102 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
               }
               const float si = (snear > sfar) ? snear : sfar;
               if (si > opt) { opt = si; cat = (snear > sfar) ? 3 : 2; }
-              int oa = a - 1, ob = bb - 1;
+              pgen = true; pgi = gi; pge = ge; pcn = cn;
               if (cat == 1) {
-                const bool amb = clip0(de + sim, LOCAL) == opt;
-                int k = amb ? 1 : (dc > 1 ? dc : 1);
-                const float gbi = TPOS ? tg[bb].x : 0.f, gbe = TPOS ? tg[bb].y : 0.f;
-                const float* prevF = rowsF + (size_t)((a - 1) & (kTRing - 1)) * PT;   // row a-1, every column, through L2
+                pcat = 1; pamb = clip0(de + sim, LOCAL) == opt;
+                pk = pamb ? 1 : (dc > 1 ? dc : 1);
+              } else if (cat == 2) {
+                pcat = 2; pamb = clip0(ef + sim, LOCAL) == opt;
+                pk = pamb ? 1 : (cf > 1 ? cf : 1);
+              } else if (cat == 3) {
+                oa = knear; ob = bb - 1;
+              }
+            }
+            // ---- which candidate: the reference keeps the FIRST k whose literal value equals the cell's (dpmatrix.h:447-486).  The
+            // scans left (chunk, tie flag); inside the chunk the wave searches together: a cell's 32 (deletion) or 16 (insertion)
+            // candidates are evaluated by as many lanes at once — two (four) cells per round, the loads of up to four (two) rounds
+            // in flight together — instead of every lane walking its own chunk while the other 60 wait.  Same arithmetic, value by
+            // value; cells with a tie (or, never seen, without a hit in their chunk) fall back to the literal walk.
+            {
+              const int lane = tid & 63;
+              const float* prevF = rowsF + (size_t)((a - 1) & (RING - 1)) * PT;   // row a-1, every column, through L2
+              const float gbi = TPOS ? tg[bb].x : 0.f, gbe = TPOS ? tg[bb].y : 0.f;
+              bool pend = pcat != 0;
+              auto fetch_i = [&](int sidx, int v) -> int { return __builtin_amdgcn_ds_bpermute(sidx, v); };
+              auto fetch_f = [&](int sidx, float v) -> float { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sidx, __builtin_bit_cast(int, v))); };
+              unsigned long long m1 = __ballot(pcat == 1 && !pamb);
+              while (m1) {
+                int La[4], Lb[4]; float pv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  La[q] = -1; Lb[q] = -1;
+                  if (m1) { La[q] = __builtin_ctzll(m1); m1 &= m1 - 1; }
+                  if (m1) { Lb[q] = __builtin_ctzll(m1); m1 &= m1 - 1; }
+                  const int sl = lane < 32 ? La[q] : Lb[q];
+                  const int sidx = (sl < 0 ? lane : sl) << 2;
+                  const int kk = fetch_i(sidx, pk) + (lane & 31), bS = fetch_i(sidx, bb);
+                  const bool live = sl >= 0 && kk >= 1 && kk <= bS - 2;
+                  pv[q] = ninf;
+                  if (live) pv[q] = (kk >= kbase) ? prev[kk] : aload(&prevF[kk]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  if (La[q] < 0) break;                            // wave-uniform
+                  const int sl = lane < 32 ? La[q] : Lb[q];
+                  const int sidx = (sl < 0 ? lane : sl) << 2;
+                  const int kk = fetch_i(sidx, pk) + (lane & 31), bS = fetch_i(sidx, bb);
+                  const bool live = sl >= 0 && kk >= 1 && kk <= bS - 2;
+                  const float optS = fetch_f(sidx, opt), simS = fetch_f(sidx, sim);
+                  const float2 tk = tg[live ? kk : 1];
+                  float g = gi_c + ge_c * (float)(bS - kk - 2);
+                  if (TPOS) g = fminr(tk.x, fetch_f(sidx, gbi)) + fminr(tk.y, fetch_f(sidx, gbe)) * (float)(bS - kk - 2);
+                  if (TAB) g = live ? del_at(kk, bS) : 0.f;
+                  float sv = pv[q];
+                  sv -= g;
+                  sv += simS;
+                  sv = clip0(sv, LOCAL);
+                  const unsigned long long hit = __ballot(live && sv == optS);
+                  if (lane == La[q] && (unsigned)hit) { ob = pk + __builtin_ctz((unsigned)hit); pend = false; }
+                  if (lane == Lb[q] && (unsigned)(hit >> 32)) { ob = pk + __builtin_ctz((unsigned)(hit >> 32)); pend = false; }
+                }
+              }
+              unsigned long long m2 = __ballot(pcat == 2 && !pamb);
+              while (m2) {
+                int Lq[2][4]; float xv[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                  for (int w4 = 0; w4 < 4; ++w4) { Lq[q][w4] = -1; if (m2) { Lq[q][w4] = __builtin_ctzll(m2); m2 &= m2 - 1; } }
+                  const int sl = lane < 16 ? Lq[q][0] : lane < 32 ? Lq[q][1] : lane < 48 ? Lq[q][2] : Lq[q][3];
+                  const int sidx = (sl < 0 ? lane : sl) << 2;
+                  const int kk = fetch_i(sidx, pk) + (lane & 15), bS = fetch_i(sidx, bb);
+                  const bool live = sl >= 0 && kk <= a0 - 2;
+                  xv[q] = ninf;
+                  if (live) xv[q] = aload(&H[(size_t)f.rq(kk) * ld + (size_t)f.rt(bS - 1)]);
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                  if (Lq[q][0] < 0) break;                         // wave-uniform
+                  const int sl = lane < 16 ? Lq[q][0] : lane < 32 ? Lq[q][1] : lane < 48 ? Lq[q][2] : Lq[q][3];
+                  const int sidx = (sl < 0 ? lane : sl) << 2;
+                  const int kk = fetch_i(sidx, pk) + (lane & 15);
+                  const bool live = sl >= 0 && kk <= a0 - 2;
+                  const float optS = fetch_f(sidx, opt), simS = fetch_f(sidx, sim);
+                  float g = fetch_f(sidx, pgi) + fetch_f(sidx, pge) * (float)(a - kk - 2);
+                  if (TAB) g = g + fetch_f(sidx, pcn);
+                  float sv = xv[q];
+                  sv -= g;
+                  sv += simS;
+                  sv = clip0(sv, LOCAL);
+                  const unsigned long long hit = __ballot(live && sv == optS);
+#pragma unroll
+                  for (int w4 = 0; w4 < 4; ++w4) {
+                    const unsigned hh = (unsigned)(hit >> (16 * w4)) & 0xFFFFu;
+                    if (lane == Lq[q][w4] && hh) { oa = pk + __builtin_ctz(hh); ob = bb - 1; pend = false; }
+                  }
+                }
+              }
+              if (pend && pcat == 1) {                              // literal walk (ties)
                 auto lit = [&](int kk, float pvv) -> float {
                   const float2 tk = tg[kk];
                   float g = (TPOS ? fminr(tk.x, gbi) : gi_c) + (TPOS ? fminr(tk.y, gbe) : ge_c) * (float)(bb - kk - 2);
@@ -925,85 +1115,71 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
                   sv += sim;
                   return clip0(sv, LOCAL);
                 };
-                bool found = false;
-                if (!amb && k < kbase) {                       // the chunk lies left of the tile: its 32 sources in one batch
-                  float xs[kBC];
-#pragma unroll
-                  for (int u = 0; u < kBC; ++u) xs[u] = aload(&prevF[k + u]);
-#pragma unroll
-                  for (int u = 0; u < kBC; ++u) {
-                    if (!found && k + u >= 1 && k + u <= bb - 2 && lit(k + u, xs[u]) == opt) { found = true; ob = k + u; }
-                  }
-                  k = bb - 2;                                    // (cannot happen) nothing matched: last candidate
-                } else {
-                  for (; k < bb - 2; ++k) {
-                    const float pvv = (k >= kbase) ? prev[k] : aload(&prevF[k]);
-                    if (lit(k, pvv) == opt) break;
-                  }
+                int k = pk;
+                for (; k < bb - 2; ++k) {
+                  const float pvv = (k >= kbase) ? prev[k] : aload(&prevF[k]);
+                  if (lit(k, pvv) == opt) break;
                 }
-                oa = a - 1; if (!found) ob = k;
-              } else if (cat == 2) {
-                const bool amb = clip0(ef + sim, LOCAL) == opt;
-                int k = amb ? 1 : (cf > 1 ? cf : 1);
-                bool found = false;
-                if (!amb) {                                      // the chunk's 16 rows in one batch
-                  float xs[kBR];
-#pragma unroll
-                  for (int u = 0; u < kBR; ++u) xs[u] = (k + u <= a0 - 2) ? aload(&H[(size_t)f.rq(k + u) * ld + colb]) : ninf;
-#pragma unroll
-                  for (int u = 0; u < kBR; ++u) {
-                    if (!found && k + u <= a0 - 2) {
-                      float sv = xs[u];
-                      sv -= ins_gap(a - (k + u) - 2);
-                      sv += sim;
-                      sv = clip0(sv, LOCAL);
-                      if (sv == opt) { found = true; oa = k + u; }
-                    }
-                  }
-                  k = a0 - 2;
-                } else {
-                  for (; k < a0 - 2; ++k) {
-                    float sv = aload(&H[(size_t)f.rq(k) * ld + colb]);
-                    sv -= ins_gap(a - k - 2);
-                    sv += sim;
-                    sv = clip0(sv, LOCAL);
-                    if (sv == opt) break;
-                  }
+                oa = a - 1; ob = k;
+              } else if (pend && pcat == 2) {
+                int k = pk;
+                for (; k < a0 - 2; ++k) {
+                  float sv = aload(&H[(size_t)f.rq(k) * ld + (size_t)f.rt(bb - 1)]);
+                  float g = pgi + pge * (float)(a - k - 2);
+                  if (TAB) g = g + pcn;
+                  sv -= g;
+                  sv += sim;
+                  sv = clip0(sv, LOCAL);
+                  if (sv == opt) break;
                 }
-                if (!found) oa = k;
-                ob = bb - 1;
-              } else if (cat == 3) {
-                oa = knear; ob = bb - 1;
+                oa = k; ob = bb - 1;
               }
-              optp = pack_ptr(f.rq(oa), f.rt(ob));
+              if (pgen) optp = pack_ptr(f.rq(oa), f.rt(ob));
             }
             if (valid) {
               H[(size_t)i * ld + jj] = opt; P[(size_t)i * ld + jj] = optp;
               rowF[bc] = opt;
-              curl[1 + tid] = opt;
+              curl[1 + lt] = opt;
               colmax = vmaxf(colmax, opt);
               const uint32_t pos = ((uint32_t)a << 16) | (uint32_t)bc;
               if (opt > lmax || (opt == lmax && pos < lpos)) { lmax = opt; lpos = pos; }   // tiles are not visited in row-major order
             } else {
-              curl[1 + tid] = ninf;
+              curl[1 + lt] = ninf;
+            }
+            if constexpr (WF) {
+              // the row's maxima over this tile's two 32-column chunks (the skip tests of later far-left scans)
+              if (prune) {
+                float rv = valid ? opt : ninf;
+#pragma unroll
+                for (int o = 1; o <= 16; o <<= 1) rv = vmaxf(rv, __shfl_xor(rv, o));
+                if ((lt & 31) == 0) delmaxF[(size_t)(kbase / 32 + (lt >> 5)) * RING + (a & (RING - 1))] = rv;
+              }
             }
           } else {
-            curl[1 + tid] = ninf;
+            curl[1 + lt] = ninf;
           }
-          if (tid == 0) curl[0] = (cb >= 1) ? aload(&rowF[kbase]) : ninf;     // column b0-1 of row a (finished in the previous tile)
-          __threadfence_block();
-          __syncthreads();
+          if constexpr (WF) {
+            if (lt == 0) curl[0] = edgeL[wave][r + 1];         // column kbase of row a (finished one step ago)
+            // row a is in LDS for this wave's next rows (LDS executes a wave's accesses in order); nothing inside the tile reads
+            // it back from L2, so its stores drain behind the next rows
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+          } else {
+            if (tid == 0) curl[0] = (cb >= 1) ? aload(&rowF[kbase]) : ninf;     // column b0-1 of row a (finished in the previous tile)
+            __threadfence_block();
+            __syncthreads();
+          }
         }
         // ============ tile epilogue: the maxima later far scans test their chunks against ==============================
         if (prune) {
           if (bv) insmaxF[(size_t)((a0 - 1) >> 4) * PT + bc] = colmax;          // this column over the rows of the block
-          {
+          if constexpr (!WF) {
             // rows a0 .. a_end x this tile's 8 chunks [kbase + 32 j, kbase + 32 j + 31]: 16 threads per row, 2 per chunk
             const int r = tid >> 4, j = (tid & 15) >> 1, half = tid & 1;
             const int a = a0 + r;
             float mxv = ninf;
             if (a <= a_end) {
-              const float* rowp = rowsF + (size_t)(a & (kTRing - 1)) * PT;
+              const float* rowp = rowsF + (size_t)(a & (RING - 1)) * PT;
               const int k0 = kbase + 32 * j + 16 * half;
               float v[16];
 #pragma unroll
@@ -1012,17 +1188,60 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
               for (int u = 0; u < 16; ++u) mxv = vmaxf(mxv, v[u]);
             }
             mxv = vmaxf(mxv, __shfl_xor(mxv, 1));
-            if (half == 0 && a <= a_end) delmaxF[(size_t)(kbase / 32 + j) * kTRing + (a & (kTRing - 1))] = mxv;
+            if (half == 0 && a <= a_end) delmaxF[(size_t)(kbase / 32 + j) * RING + (a & (RING - 1))] = mxv;
+            __threadfence_block();
+            __syncthreads();
           }
-          __threadfence_block();
-          __syncthreads();
         }
+      }
+    };
+    if constexpr (!WF) {
+      for (int a0 = 1; a0 <= nQ - 1; a0 += kBR) {
+        set_prio(a0);
+        for (int cb = 0; cb < ntiles; ++cb) do_tile(a0, cb);
+      }
+    } else {
+      // Wavefront over (row block, 64-column tile): wave w owns the row blocks w, w+4, w+8, ... and sweeps each left to right.  Its
+      // tile (A, c) needs tile (A-1, c) — row a0-1 and the maxima of the block above — so it starts its j-th tile when the wave
+      // that owns the block above has finished ITS j-th tile; wave 0 follows wave 3's previous block the same way (that needs
+      // >= 4 tiles per sweep: narrower templates get empty ones).  Inside a tile nothing is shared between waves — the 64 columns'
+      // own sources are this wave's previous rows, in LDS — so there is no workgroup barrier at all: a wave publishes the number
+      // of tiles it has finished in LDS (after its stores have reached L2) and the next one polls that word.  Tile times differ
+      // (which far chunks are scanned depends on the data); a wave may run up to a sweep ahead of its follower, which absorbs that.
+      // No deadlock: tile j of wave w waits for a tile with a smaller (block, column) only, and every wave of the workgroup is resident.
+      const int NB = (nQ - 1 + kBR - 1) / kBR;
+      const int sweep = ntiles < 4 ? 4 : ntiles;
+      const int my_tiles = (NB > wave ? (NB - wave + 3) / 4 : 0) * sweep;
+      const int src = (wave + 3) & 3;                      // the wave that owns the block above
+      for (int j = 0; j < my_tiles; ++j) {
+        const int g = j / sweep, c = j - g * sweep;
+        const int a0 = 1 + kBR * (wave + 4 * g);
+        const int need = wave ? j + 1 : j - sweep + 1;     // tiles the wave above must have finished
+        if (need > 0) {
+          // (bounded: a wait of seconds can only be a defect — the pair's maximum is poisoned instead of the GPU hanging)
+          int spins = 0;
+          while (__hip_atomic_load(&wdone[src], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1 << 24)) { lmax = __builtin_nanf(""); lpos = 0u; break; }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        if (c == 0) set_prio(a0);
+        if (c < ntiles) do_tile(a0, c);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the tile's stores have been acknowledged by L2
+        if (lt == 0) __hip_atomic_store(&wdone[wave], j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
   }
   if (dbg && (threadIdx.x & 63) == 0) {
-    atomicAdd(&dbg[0], (unsigned long long)n_tested_d); atomicAdd(&dbg[1], (unsigned long long)n_skip_d);
-    atomicAdd(&dbg[2], (unsigned long long)n_tested_i); atomicAdd(&dbg[3], (unsigned long long)n_skip_i);
+    if (dbg[4] == 2) {                                  // exact_debug 2: how long the waves ran (sum, longest, ~shortest, count; 1024 ticks)
+      const unsigned long long dur = (__builtin_amdgcn_s_memtime() - t_begin) >> 10;
+      atomicAdd(&dbg[0], dur); atomicMax(&dbg[1], dur); atomicMax(&dbg[2], ~dur); atomicAdd(&dbg[3], 1ull);
+      if (smax_arr && threadIdx.x == 0) const_cast<float*>(smax_arr)[blockIdx.x] = (float)dur;   // (read at the start; the host lists the slowest pairs)
+    } else {
+      atomicAdd(&dbg[0], (unsigned long long)n_tested_d); atomicAdd(&dbg[1], (unsigned long long)n_skip_d);
+      atomicAdd(&dbg[2], (unsigned long long)n_tested_i); atomicAdd(&dbg[3], (unsigned long long)n_skip_i);
+    }
   }
   float m = lmax; uint32_t p = lpos;
 #pragma unroll
@@ -1109,7 +1328,11 @@ int launch_dp_exact_blocked(aln_batch* b) {
   const int ptt = (mx + 1 <= 4 * kTW ? 4 : mx + 1 <= 8 * kTW ? 8 : mx + 1 <= 12 * kTW ? 12 : 16) * kTW + kBPad;          // row pitch of the scratch rows: a compile-time constant of the kernel
   // tiled kernel: + one row of chunk maxima + one row of column maxima per 16-row block (the skip tests of the far scans) + max|S| per pair
   const int q_blocks = (b->maxQ + kBR - 1) / kBR + 1;
-  const size_t need = tiled ? (size_t)(6 * kBR + kTRing + 3 + q_blocks) * ptt * (size_t)b->n_pairs + (size_t)b->n_pairs + 64
+  // the wavefront form keeps 17 rows of every wave's tile in LDS; beyond 64 KB per workgroup (the widest templates with Gn2Eval's tables) the 256-column form runs
+  const bool wavefront = ctx->hints.exact_wavefront != 0 && ((size_t)2 * ptt + 4 * kWHist + (gn2 ? ptt : 0)) * sizeof(float) <= 65536;
+  const int ring = wavefront ? kWRing : kTRing;
+  const size_t tiled_floats = (size_t)(6 * kBR + ring + 2 + ring / 32 + q_blocks) * ptt;     // per pair, as the kernel lays them out
+  const size_t need = tiled ? tiled_floats * (size_t)b->n_pairs + (size_t)b->n_pairs + 64
                             : blocked_scratch_floats(ns) * (size_t)b->n_pairs;
   if (b->xscratch_floats < need) {
     if (b->d_xscratch) { ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); hipFree(b->d_xscratch); b->d_xscratch = nullptr; b->xscratch_floats = 0; }
@@ -1129,7 +1352,7 @@ int launch_dp_exact_blocked(aln_batch* b) {
   const bool tpos = b->gapdev.model == ALN_GAP_AFFINE_TPOS_MIN;
   int rc;
   if (tiled) {
-    const size_t lds = ((size_t)2 * ptt + 2 * kTLoc + (gn2 ? ptt : 0)) * sizeof(float);
+    const size_t lds = ((size_t)2 * ptt + (wavefront ? 4 * kWHist : 2 * kTLoc) + (gn2 ? ptt : 0)) * sizeof(float);
     const int rev = (int)(b->direction == ALN_REV);
     // Gn2Eval's model: per pair the frame-ordered deletion table.  Forward builds read the caller's tables; reverse builds their
     // flipped transposes tabR[x][y] = tab[T-1-y][T-1-x] (made here, once per upload), so that a thread's column b stays the
@@ -1169,37 +1392,54 @@ int launch_dp_exact_blocked(aln_batch* b) {
     float smax_const = 0.f;
     if (sub) { for (float v : b->h_table) smax_const = std::max(smax_const, std::fabs(v)); }
     else if (prune) {
-      d_smax = b->d_xscratch + (size_t)(6 * kBR + kTRing + 3 + q_blocks) * ptt * (size_t)b->n_pairs;
+      d_smax = b->d_xscratch + tiled_floats * (size_t)b->n_pairs;
       hipLaunchKernelGGL(plane_absmax_kernel, dim3(b->n_pairs), dim3(256), 0, ctx->stream, b->d_pairs, b->d_S, d_smax);
       ALN_HIP_CHECK(ctx, hipGetLastError());
     }
+    // the launch's progress word (exact_alt_prio 2), in the scratch's tail beside the debug counters
+    unsigned int* d_gprog = reinterpret_cast<unsigned int*>(b->d_xscratch + (need - 32));
+    ALN_HIP_CHECK(ctx, hipMemsetAsync(d_gprog, 0, 4, ctx->stream));
     unsigned long long* d_dbg = nullptr;
     if (ctx->hints.exact_debug) {
       d_dbg = reinterpret_cast<unsigned long long*>(b->d_xscratch + ((need - 16) & ~(size_t)1));
-      ALN_HIP_CHECK(ctx, hipMemsetAsync(d_dbg, 0, 32, ctx->stream));
+      const unsigned long long init[5] = {0, 0, 0, 0, (unsigned long long)ctx->hints.exact_debug};
+      ALN_HIP_CHECK(ctx, hipMemcpyAsync(d_dbg, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
     }
 #define ALN_TLAUNCH(PTC, GM_, LC)                                                                                                \
-    hipLaunchKernelGGL((dp_exact_tiled_kernel<PTC, GM_, LC>), dim3(b->n_pairs), dim3(kTW), lds, ctx->stream, b->d_pairs, proto,    \
+    if (wavefront) ALN_TLAUNCH_W(PTC, GM_, LC, true); else ALN_TLAUNCH_W(PTC, GM_, LC, false)
+#define ALN_TLAUNCH_W(PTC, GM_, LC, WF_)                                                                                         \
+    hipLaunchKernelGGL((dp_exact_tiled_kernel<PTC, GM_, LC, WF_>), dim3(b->n_pairs), dim3(kTW), lds, ctx->stream, b->d_pairs, proto,    \
                        sub ? b->d_qcodes : nullptr, sub ? b->d_tcodes : nullptr, (tpos || gn2) ? b->d_tgi : nullptr,               \
                        (tpos || gn2) ? b->d_tge : nullptr, b->d_H, b->d_P, sub ? nullptr : b->d_S, b->d_res, rev, b->d_xscratch,   \
-                       alt_prio, delF, b->d_pair_deloff, prune, q_blocks, d_smax, smax_const, d_dbg)
+                       alt_prio, delF, b->d_pair_deloff, prune, q_blocks, d_smax, smax_const, d_dbg, d_gprog)
 #define ALN_TLAUNCH_P(PTC)                                                                                                       \
-    do { if (gn2) { if (b->islocal) ALN_TLAUNCH(PTC, 2, true); else ALN_TLAUNCH(PTC, 2, false); }                                \
-         else if (tpos) { if (b->islocal) ALN_TLAUNCH(PTC, 1, true); else ALN_TLAUNCH(PTC, 1, false); }                          \
-         else { if (b->islocal) ALN_TLAUNCH(PTC, 0, true); else ALN_TLAUNCH(PTC, 0, false); } } while (0)
+    do { if (gn2) { if (b->islocal) { ALN_TLAUNCH(PTC, 2, true); } else { ALN_TLAUNCH(PTC, 2, false); } }                        \
+         else if (tpos) { if (b->islocal) { ALN_TLAUNCH(PTC, 1, true); } else { ALN_TLAUNCH(PTC, 1, false); } }                  \
+         else { if (b->islocal) { ALN_TLAUNCH(PTC, 0, true); } else { ALN_TLAUNCH(PTC, 0, false); } } } while (0)
     if (ptt == 4 * kTW + kBPad) ALN_TLAUNCH_P(4 * kTW + kBPad);
     else if (ptt == 8 * kTW + kBPad) ALN_TLAUNCH_P(8 * kTW + kBPad);
     else if (ptt == 12 * kTW + kBPad) ALN_TLAUNCH_P(12 * kTW + kBPad);
     else ALN_TLAUNCH_P(16 * kTW + kBPad);
 #undef ALN_TLAUNCH_P
+#undef ALN_TLAUNCH_W
 #undef ALN_TLAUNCH
     ALN_HIP_CHECK(ctx, hipGetLastError());
     if (d_dbg) {                                         // chunks tested / skipped, far-left deletions then far insertions (per wave)
       ALN_HIP_CHECK(ctx, hipMemcpyAsync(b->exact_stats, d_dbg, 32, hipMemcpyDeviceToHost, ctx->stream));
       ALN_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->hints.exact_debug == 2 && d_smax) {
+        std::vector<float> dur(b->n_pairs);
+        ALN_HIP_CHECK(ctx, hipMemcpy(dur.data(), d_smax, (size_t)b->n_pairs * 4, hipMemcpyDeviceToHost));
+        std::vector<int> idx(b->n_pairs);
+        for (int q = 0; q < b->n_pairs; ++q) idx[q] = q;
+        std::sort(idx.begin(), idx.end(), [&](int x, int y) { return dur[x] > dur[y]; });
+        fprintf(stderr, "[exact_debug 2] slowest pairs (wave 0, 1024 ticks):");
+        for (int q = 0; q < b->n_pairs && q < 12; ++q) fprintf(stderr, " %d:%.0f", idx[q], dur[idx[q]]);
+        fprintf(stderr, "; median %.0f\n", dur[idx[b->n_pairs / 2]]);
+      }
     }
     b->kernel_name = std::string("dp_exact_tiled_kernel<") + (gn2 ? "gn2tab," : tpos ? "tpos," : "const,") + (b->islocal ? "local" : "global") +
-                     (b->direction == ALN_REV ? ",rev>" : ",fwd>");
+                     (b->direction == ALN_REV ? ",rev" : ",fwd") + (wavefront ? ",wavefront>" : ">");
     return ALN_OK;
   }
   switch (ns) {

@@ -191,7 +191,13 @@ int aln_has_gfx950(void);
  *   "tag_solo"                      1: templates of up to 2048 columns run in the one-wave-per-pair kernel (dp_affine_solo.hip: no
  *                                   barriers; wants >= 2048 pairs in flight, i.e. two 1024-pair launches on two streams)
  *   "dp_variant_nw" "dp_variant_r" "dp_variant_x"   force a row-sweep instantiation (0 = automatic)
- *   "exact_tiles" "exact_literal" "exact_alt_prio" "score_packed" "enum_node_cap" "tag_lag"
+ *   "exact_tiles" "exact_literal" "score_packed" "enum_node_cap" "tag_lag"
+ *   "exact_wavefront"               tiled exact-order kernel: 1 (default) = 64-column tiles, the four waves of a pair on four row
+ *                                   blocks, no workgroup barrier; 0 = 256-column tiles with a barrier per row.  Same planes.
+ *   "exact_alt_prio"                tiled exact-order kernel, wave priorities: 2 (default) = by progress (a wave ahead of the
+ *                                   launch's average yields), 1 = rotation over the resident waves, 0 = none
+ *   "exact_prune"                   1 (default): far candidate chunks that provably cannot matter are skipped (bit-exact); 0: off
+ *   "exact_debug"                   1: aln_batch_last_exact_stats reports tested / skipped far chunks; 2: the waves' run times
  *   "enum_waves"                    ConstrainedNearOptimal / UnconstrainedNearOptimal / KSConstrainedNearOptimal search: waves per pair
  *                                   (2..16, enumerate_par.hip);
  *                                   1 = the one-wave kernel; 0 (default) = 16.  Same sets, same order.

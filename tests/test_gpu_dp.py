@@ -356,11 +356,13 @@ def test_exact_chunk_skipping_is_invisible(direction, blosum62):
     bounds, a rounding margin — csrc/dp_exact_blocked.hip).  On pairs with dozens of row blocks and several column tiles: the
     planes with the skipping on equal the planes with it off AND the oracle's, bit for bit, pointers included — fractional
     constant gaps and integer gaps (ties everywhere) over BLOSUM scores, position-minimum gaps over fractional planes; global,
-    local, semi-local; the counters show that chunks really were skipped."""
+    local, semi-local; the counters show that chunks really were skipped.  Both forms of the kernel: the wavefront of 64-column tiles
+    (no workgroup barrier, the default) and the 256-column tiles with a barrier per row."""
     alpha, table = blosum62
     d = DIRS[direction]
     od = orc.FWD if direction == "fwd" else orc.REV
     ctx = gpu_util.ctx()
+    FORMS = ((1, 1), (0, 1), (1, 0))          # (skipping, wavefront form): the default, the same without skipping, the 256-column form
     shapes = [(620, 900), (1100, 530), (300, 1400)]
     pairs = []
     for n, (ql, tl) in enumerate(shapes):
@@ -368,19 +370,21 @@ def test_exact_chunk_skipping_is_invisible(direction, blosum62):
         pairs.append((q[:ql], t[-tl:]))
     for mode, gi, ge, algo in ((1, 4.73, 0.34, aln_amd.DP_AUTO), (3, 11, 1, aln_amd.DP_EXACT), (4, 2.5, 0.25, aln_amd.DP_AUTO)):
         got = {}
-        for prune in (1, 0):
-            with ctx.hints(exact_prune=prune, exact_debug=1):
+        for prune, wf in FORMS:
+            with ctx.hints(exact_prune=prune, exact_debug=1, exact_wavefront=wf):
                 b = aln_amd.Batch(ctx, [p[0] for p in pairs], [p[1] for p in pairs])
                 b.dp_submatrix(alpha, table, mode, gi, ge, d, algo)
-                assert "dp_exact_tiled" in b.kernel_name()
-                got[prune] = [b.get_cells(p) for p in range(len(pairs))]
+                assert "dp_exact_tiled" in b.kernel_name() and ("wavefront" in b.kernel_name()) == bool(wf), b.kernel_name()
+                got[(prune, wf)] = [b.get_cells(p) for p in range(len(pairs))]
                 st = b.last_exact_stats()
                 if prune:
                     assert st[1] > 0 and st[3] > 0 and st[1] <= st[0] and st[3] <= st[2], st      # chunks really were skipped
                 b.close()
+        got[1], got[0] = got[(1, 1)], got[(0, 1)]
         for p, (q, t) in enumerate(pairs):
-            for x, y in zip(got[1][p], got[0][p]):
-                assert np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32)), (mode, p, direction)
+            for other in FORMS[1:]:
+                for x, y in zip(got[1][p], got[other][p]):
+                    assert np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32)), (mode, p, direction, other)
             S = orc.sim_submatrix(q, t, alpha, table)
             rc, D0, PQ0, PT0 = orc.dp_build(S, orc.Gap(mode, gi, ge), od)
             D, PQ, PT = got[1][p]
@@ -399,21 +403,23 @@ def test_exact_chunk_skipping_is_invisible(direction, blosum62):
         tges.append((np.float32(0.34) * pi).astype(np.float32))
     for mode in (1, 3, 4):
         got = {}
-        for prune in (1, 0):
-            with ctx.hints(exact_prune=prune, exact_debug=1):
+        for prune, wf in FORMS:
+            with ctx.hints(exact_prune=prune, exact_debug=1, exact_wavefront=wf):
                 b = aln_amd.Batch(ctx, ["A" * (Q - 2) for Q, T in dims], ["A" * (T - 2) for Q, T in dims])
                 b.dp_simmatrix(planes, mode, 0, 0, d, tgi=np.concatenate(tgis), tge=np.concatenate(tges))
-                assert "dp_exact_tiled" in b.kernel_name()
-                got[prune] = [b.get_cells(p) for p in range(len(dims))]
+                assert "dp_exact_tiled" in b.kernel_name() and ("wavefront" in b.kernel_name()) == bool(wf), b.kernel_name()
+                got[(prune, wf)] = [b.get_cells(p) for p in range(len(dims))]
                 st = b.last_exact_stats()
                 if prune:
                     assert st[1] > 0 and st[3] > 0 and st[1] <= st[0] and st[3] <= st[2], st
                 else:
                     assert st[0] == 0 and st[2] == 0, st               # nothing is tested when the skipping is off
                 b.close()
+        got[1] = got[(1, 1)]
         for p, S in enumerate(planes):
-            for x, y in zip(got[1][p], got[0][p]):
-                assert np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32)), (mode, p, direction)
+            for other in FORMS[1:]:
+                for x, y in zip(got[1][p], got[other][p]):
+                    assert np.array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32)), (mode, p, direction, other)
             rc, D0, PQ0, PT0 = orc.dp_build(S, orc.Gap(mode, tgi=tgis[p], tge=tges[p]), od)
             D, PQ, PT = got[1][p]
             assert np.array_equal(D.view(np.uint32), D0.view(np.uint32)), (mode, p, direction)
