@@ -171,6 +171,7 @@ def secondary_configs(aln_amd, ctx, alphabet, table, qs, ts, length):
         b.dp_hmap2(qpool, tpool, aln_amd.GLOBAL, 4.73, 0.34, 0.5, 1.0, 0.12)
         sc, _, st = b.optimal(want_pairs=False)
         dt = time.perf_counter() - t0
+        assert np.all(np.isfinite(sc)), "config 3: a profile pair without a finite score (a degenerate synthetic profile would bound the launch)"
         best = dt if best is None else min(best, dt)
     inner = n * float(length + 2) ** 2 * (2 * length + 4) / 2.0
     out["c3"] = {"workload": "config 3: %d pairs %dx%d (%d + %d distinct synthetic HMAP profiles), Hmap2Eval similarity + z-normalisation "
