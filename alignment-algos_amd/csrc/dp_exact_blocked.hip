@@ -56,6 +56,26 @@ __device__ __forceinline__ void submax4_sv(float& c0, float& c1, float& c2, floa
       : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
       : "s"(s0), "s"(s1), "s"(s2), "s"(s3), "v"(g));
 }
+// Two candidates per row at once: (sub, sub, max3) instead of 2 x (sub, max) — v_max_f32 and v_max3_f32 both issue at half rate on
+// gfx950, so the second maximum is free.  Four rows per statement, subtractions first (see submax4_vv).
+__device__ __forceinline__ void submax3x4_vv(float& c0, float& c1, float& c2, float& c3, float xa, float a0, float a1, float a2, float a3,
+                                             float xb, float b0, float b1, float b2, float b3) {
+  float t0, t1, t2, t3, t4, t5, t6, t7;
+  asm("v_sub_f32 %0, %12, %13\n\tv_sub_f32 %1, %12, %14\n\tv_sub_f32 %2, %12, %15\n\tv_sub_f32 %3, %12, %16\n\t"
+      "v_sub_f32 %4, %17, %18\n\tv_sub_f32 %5, %17, %19\n\tv_sub_f32 %6, %17, %20\n\tv_sub_f32 %7, %17, %21\n\t"
+      "v_max3_f32 %8, %8, %0, %4\n\tv_max3_f32 %9, %9, %1, %5\n\tv_max3_f32 %10, %10, %2, %6\n\tv_max3_f32 %11, %11, %3, %7"
+      : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+      : "v"(xa), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(xb), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+}
+__device__ __forceinline__ void submax3x4_sv(float& c0, float& c1, float& c2, float& c3, float sa0, float sa1, float sa2, float sa3, float ga,
+                                             float sb0, float sb1, float sb2, float sb3, float gb) {
+  float t0, t1, t2, t3, t4, t5, t6, t7;
+  asm("v_sub_f32 %0, %12, %16\n\tv_sub_f32 %1, %13, %16\n\tv_sub_f32 %2, %14, %16\n\tv_sub_f32 %3, %15, %16\n\t"
+      "v_sub_f32 %4, %17, %21\n\tv_sub_f32 %5, %18, %21\n\tv_sub_f32 %6, %19, %21\n\tv_sub_f32 %7, %20, %21\n\t"
+      "v_max3_f32 %8, %8, %0, %4\n\tv_max3_f32 %9, %9, %1, %5\n\tv_max3_f32 %10, %10, %2, %6\n\tv_max3_f32 %11, %11, %3, %7"
+      : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+      : "s"(sa0), "s"(sa1), "s"(sa2), "s"(sa3), "v"(ga), "s"(sb0), "s"(sb1), "s"(sb2), "s"(sb3), "v"(gb));
+}
 // loads served by L2 (the planes are written by other threads of this workgroup; L1 lines may predate those writes)
 __device__ __forceinline__ float aload(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int aloadi(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -68,6 +88,11 @@ struct ScanState {
   int cidx[NS];
 };
 
+// the value N lanes down the same row of 16 lanes (-inf where the row ends)
+template <int N>
+__device__ __forceinline__ float row_shr_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp((int)0xFF800000, __builtin_bit_cast(int, v), 0x110 + N, 0xF, 0xF, false));
+}
 __device__ __forceinline__ float vmax3f(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
 // k in [k0, k1) (both multiples of kBC), slots JJ..NS-1 active; MASK: slot JJ is in its triangular tail (fd < 0 = beyond b-2).
@@ -725,13 +750,20 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
                 x[u] = (k <= a0 - 2) ? aload(&H[(size_t)f.rq(k) * ld + colb]) : ninf;
               }
 #pragma unroll
-              for (int u = 0; u < kBR; ++u) {
+              for (int u = 0; u < kBR; u += 2) {               // two source rows per step: the window as row u sees it, then slid by one
+                float wa[HW], wb[HW];
 #pragma unroll
-                for (int r = 0; r < HW; r += 4)
-                  submax4_vv(cm[r], cm[r + 1], cm[r + 2], cm[r + 3], x[u], W[(r - u) & (HW - 1)], W[(r + 1 - u) & (HW - 1)],
-                             W[(r + 2 - u) & (HW - 1)], W[(r + 3 - u) & (HW - 1)]);
+                for (int r = 0; r < HW; ++r) wa[r] = W[(r - u) & (HW - 1)];
                 fn -= 1.0f;
                 W[(HW - 1 - u) & (HW - 1)] = TAB ? (gi + ge * fn) + cn : gi + ge * fn;
+#pragma unroll
+                for (int r = 0; r < HW; ++r) wb[r] = W[(r - u - 1) & (HW - 1)];
+                fn -= 1.0f;
+                W[(HW - 2 - u) & (HW - 1)] = TAB ? (gi + ge * fn) + cn : gi + ge * fn;
+#pragma unroll
+                for (int r = 0; r < HW; r += 4)
+                  submax3x4_vv(cm[r], cm[r + 1], cm[r + 2], cm[r + 3], x[u], wa[r], wa[r + 1], wa[r + 2], wa[r + 3],
+                               x[u + 1], wb[r], wb[r + 1], wb[r + 2], wb[r + 3]);
               }
 #pragma unroll
               for (int r = 0; r < HW; ++r) {
@@ -758,19 +790,28 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
                 for (int t = 0; t < IG; ++t) cmxv[t] = (t < ng) ? aload(cmaxcol + (size_t)(jg - t) * PT) : ninf;
 #pragma unroll
                 for (int i = 0; i < HW; ++i) thr[i] = (a0 + HW * h + i > a_end) ? __builtin_inff() : prune_thr(m[i], ceps);
+                // one comparison first: the window's nearest row has the smallest gap, so its bound against the LOWEST of the eight
+                // thresholds dominates all eight row tests; only a chunk that fails it gets them (a tenth does)
+                float thr_min = thr[0];
+#pragma unroll
+                for (int i = 1; i < HW; ++i) thr_min = vminf(thr_min, thr[i]);
                 todo = 0u;
 #pragma unroll
                 for (int t = 0; t < IG; ++t) {
                   if (t < ng) {
                     const float fn0 = (float)(a0 + HW * h - 2 - (1 + 16 * (jg - t) + 15));   // n of (first window row, nearest row of the chunk)
-                    bool ok = true;
+                    float gl0 = gi + ge * fn0;
+                    if (TAB) gl0 = gl0 + cn;
+                    if (__ballot((cmxv[t] - gl0 < thr_min) || !lane_live) != ~0ull) {
+                      bool ok = true;
 #pragma unroll
-                    for (int i = 0; i < HW; ++i) {
-                      float gl = gi + ge * (fn0 + (float)i);
-                      if (TAB) gl = gl + cn;
-                      ok = ok && (cmxv[t] - gl < thr[i]);
+                      for (int i = 0; i < HW; ++i) {
+                        float gl = gi + ge * (fn0 + (float)i);
+                        if (TAB) gl = gl + cn;
+                        ok = ok && (cmxv[t] - gl < thr[i]);
+                      }
+                      if (__ballot(ok || !lane_live) != ~0ull) todo |= 1u << t;
                     }
-                    if (__ballot(ok || !lane_live) != ~0ull) todo |= 1u << t;
                   }
                 }
                 n_tested_i += (unsigned)ng;
@@ -841,16 +882,26 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
                   for (int u = 0; u < 4; ++u) gt[u] = delF[(size_t)(k + u) * TT + b];      // k + u < kbase <= b - 1: inside the table
                 }
                 swait_lgkm0();
+                float g4[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                   const float gi = TPOS ? vmin_sv(gk[u], gib) : gi_c;
                   const float ge = TPOS ? vmin_sv(ek[u], geb) : ge_c;
-                  const float g = TAB ? gt[u] : gi + ge * fd;
+                  g4[u] = TAB ? gt[u] : gi + ge * fd;
                   fd -= 1.0f;
-                  if (k + u == 0) continue;              // column 0 is never a source (dpmatrix.h:459 starts at t0+1)
+                }
 #pragma unroll
-                  for (int r = 0; r < kBR; r += 4)
-                    submax4_sv(cm[r], cm[r + 1], cm[r + 2], cm[r + 3], src[r][u], src[r + 1][u], src[r + 2][u], src[r + 3][u], g);
+                for (int u = 0; u < 4; u += 2) {
+                  if (u == 0 && k == 0) {                  // column 0 is never a source (dpmatrix.h:459 starts at t0+1): column 1 alone
+#pragma unroll
+                    for (int r = 0; r < kBR; r += 4)
+                      submax4_sv(cm[r], cm[r + 1], cm[r + 2], cm[r + 3], src[r][1], src[r + 1][1], src[r + 2][1], src[r + 3][1], g4[1]);
+                  } else {
+#pragma unroll
+                    for (int r = 0; r < kBR; r += 4)
+                      submax3x4_sv(cm[r], cm[r + 1], cm[r + 2], cm[r + 3], src[r][u], src[r + 1][u], src[r + 2][u], src[r + 3][u], g4[u],
+                                   src[r][u + 1], src[r + 1][u + 1], src[r + 2][u + 1], src[r + 3][u + 1], g4[u + 1]);
+                  }
                 }
               }
 #pragma unroll
@@ -871,6 +922,16 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
               float thr[kBR];
 #pragma unroll
               for (int r = 0; r < kBR; ++r) thr[r] = (r < r_lo || r > r_hi) ? __builtin_inff() : prune_thr(m[r], ceps);
+              // one comparison first: the chunk's maximum over the 16 rows (a DPP maximum down the 16 lanes that hold them) against
+              // the LOWEST of the sixteen thresholds dominates the sixteen row tests; only a chunk that fails it gets them
+              float thr_min = thr[0];
+#pragma unroll
+              for (int r = 1; r < kBR; ++r) thr_min = vminf(thr_min, thr[r]);
+              float mxall = ((ln & 15) < r_lo || (ln & 15) > r_hi) ? ninf : curv;      // rows that are no targets do not count
+              mxall = vmaxf(mxall, row_shr_f<1>(mxall));
+              mxall = vmaxf(mxall, row_shr_f<2>(mxall));
+              mxall = vmaxf(mxall, row_shr_f<4>(mxall));
+              mxall = vmaxf(mxall, row_shr_f<8>(mxall));                              // lane 16 t + 15: chunk gbase - t
               todo = 0u;
 #pragma unroll
               for (int t = 0; t < 4; ++t) {
@@ -879,13 +940,16 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
                   const float2 cmn = cminl[c];
                   const float dist = (float)(b - (c * kBC + kBC - 1) - 2);
                   const float g_lb = (TPOS ? fminr(cmn.x, gib) : gi_c) + (TPOS ? fminr(cmn.y, geb) : ge_c) * dist;
-                  bool ok = true;
+                  const float mxc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mxall), 16 * t + 15));
+                  if (__ballot((mxc - g_lb < thr_min) || !bv) != ~0ull) {
+                    bool ok = true;
 #pragma unroll
-                  for (int r = 0; r < kBR; ++r) {
-                    const float mx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, curv), 16 * t + r));
-                    ok = ok && (mx - g_lb < thr[r]);
+                    for (int r = 0; r < kBR; ++r) {
+                      const float mx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, curv), 16 * t + r));
+                      ok = ok && (mx - g_lb < thr[r]);
+                    }
+                    if (__ballot(ok || !bv) != ~0ull) todo |= 1u << t;
                   }
-                  if (__ballot(ok || !bv) != ~0ull) todo |= 1u << t;
                 }
               }
               n_tested_d += (unsigned)ng;
