@@ -99,7 +99,24 @@ __device__ __forceinline__ float vmax3f(float a, float b, float c) { float r; as
 // The candidate chain (min, min, mul, add, sub, max) is evaluated STAGE by stage over several independent candidates with
 // scheduling barriers in between: written chain by chain the compiler issues each chain back to back, and with 2 waves per
 // SIMD the dependent-issue latency of those 6 instructions is what the loop then runs at.
-template <int JJ, int NS, bool TPOS, bool MASK>
+// EXM (with MASK, one slot): the lanes' columns are consecutive, so "k <= b - 2" is "lane >= k - k0 + 1" — a mask known without
+// a comparison.  The candidate's maximum is then taken under that mask in EXEC (s_and_b64 + v_max_f32) instead of
+// (v_cmp, v_cndmask, half a v_max3): 1 half-rate VALU operation per candidate instead of 2.5.
+__device__ __forceinline__ unsigned long long lanes_from(int t) { return t >= 64 ? 0ull : (~0ull << (t < 0 ? 0 : t)); }
+__device__ __forceinline__ void max4_under_masks(float& c, float d0, float d1, float d2, float d3, unsigned long long m0, unsigned long long m1,
+                                                 unsigned long long m2, unsigned long long m3) {
+  unsigned long long sv;
+  asm volatile("s_mov_b64 %[sv], exec\n\t"
+               "s_and_b64 exec, %[sv], %[m0]\n\tv_max_f32 %[c], %[c], %[d0]\n\t"
+               "s_and_b64 exec, %[sv], %[m1]\n\tv_max_f32 %[c], %[c], %[d1]\n\t"
+               "s_and_b64 exec, %[sv], %[m2]\n\tv_max_f32 %[c], %[c], %[d2]\n\t"
+               "s_and_b64 exec, %[sv], %[m3]\n\tv_max_f32 %[c], %[c], %[d3]\n\t"
+               "s_mov_b64 exec, %[sv]"
+               : [c] "+v"(c), [sv] "=&s"(sv)
+               : [d0] "v"(d0), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3)
+               : "scc");
+}
+template <int JJ, int NS, bool TPOS, bool MASK, bool EXM = false>
 __device__ __forceinline__ void scan_range(ScanState<NS>& s, const float* __restrict__ prev, const float2* __restrict__ tg, int k0,
                                            int k1, float gi_c, float ge_c) {
   const float ninf = -__builtin_inff();
@@ -169,14 +186,21 @@ __device__ __forceinline__ void scan_range(ScanState<NS>& s, const float* __rest
 #pragma unroll
           for (int j = 0; j < NA; ++j) {
             gi[u][j] = pk[u] - gi[u][j];
-            if (MASK && j == 0) gi[u][j] = (fdu[u][j] >= 0.f) ? gi[u][j] : ninf;
+            if (MASK && !EXM && j == 0) gi[u][j] = (fdu[u][j] >= 0.f) ? gi[u][j] : ninf;
           }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MASK && EXM && NA == 1) {
+          const int t0 = kc - k0 + u4 + 1;                  // candidate k0 + j counts for the lanes >= j + 1
+          max4_under_masks(s.cm[JJ], gi[0][0], gi[1][0], gi[2][0], gi[3][0], lanes_from(t0), lanes_from(t0 + 1), lanes_from(t0 + 2),
+                           lanes_from(t0 + 3));
+          s.fd[JJ] -= 4.0f;
+        } else {
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-          const float a = vmax3f(s.cm[JJ + j], gi[0][j], gi[1][j]);
-          s.cm[JJ + j] = vmax3f(a, gi[2][j], gi[3][j]);
-          s.fd[JJ + j] -= 4.0f;
+          for (int j = 0; j < NA; ++j) {
+            const float a = vmax3f(s.cm[JJ + j], gi[0][j], gi[1][j]);
+            s.cm[JJ + j] = vmax3f(a, gi[2][j], gi[3][j]);
+            s.fd[JJ + j] -= 4.0f;
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1037,7 +1061,7 @@ __global__ __launch_bounds__(kTW, 4) void dp_exact_tiled_kernel(const PairDesc* 
                 }
               } else {
                 scan_range<0, 1, TPOS, false>(s, prev, tg, kbase, tail, gi_c, ge_c);
-                scan_range<0, 1, TPOS, true>(s, prev, tg, tail, tail + 64, gi_c, ge_c);
+                scan_range<0, 1, TPOS, true, true>(s, prev, tg, tail, tail + 64, gi_c, ge_c);
               }
               const float dm = s.m[0], de = s.e[0]; const int dc = s.cidx[0];
               // ---- insertions ---------------------------------------------------------------------------------------
