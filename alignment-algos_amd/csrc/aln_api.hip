@@ -172,7 +172,7 @@ int aln_batch_create(aln_ctx* ctx, const aln_seqs* queries, const aln_seqs* temp
 
 void aln_batch_destroy(aln_batch* b) {
   if (!b) return;
-  hipFree(b->d_pairs); hipFree(b->d_qcodes); hipFree(b->d_tcodes); hipFree(b->d_H); hipFree(b->d_P); hipFree(b->d_S);
+  hipFree(b->d_pairs); hipFree(b->d_qcodes); hipFree(b->d_tcodes); hipFree(b->d_H); hipFree(b->d_P); hipFree(b->d_S); hipFree(b->d_sabs);
   hipFree(b->d_res); hipFree(b->d_table32); hipFree(b->d_tablef); hipFree(b->d_tgi); hipFree(b->d_tge);
   hipFree(b->d_path); hipFree(b->d_bounds); hipFree(b->d_xscratch); hipFree(b->d_tagq); hipFree(b->d_tagstate); hipFree(b->d_deltabR); hipFree(b->d_pair_deloff);
   aln::free_string_buffers(b);
@@ -302,6 +302,7 @@ int upload_simplanes(aln_batch* b, const aln_sim* sim, bool* integral) {
       float v = src[k];
       if (!(v == (float)(int)v) || fabsf(v) > 4096.f) integ = false;
     }
+    b->sabs_valid = false;                                 // the caller's planes replace what hmap2_apply_kernel described
     ALN_HIP_CHECK(ctx, hipMemcpy2DAsync(b->d_S + d.plane_off, (size_t)d.ld * 4, src, (size_t)d.T * 4, (size_t)d.T * 4, d.Q,
                                         hipMemcpyHostToDevice, ctx->stream));
   }

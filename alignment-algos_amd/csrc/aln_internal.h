@@ -116,6 +116,8 @@ struct aln_batch {
   aln::PairDesc* d_pairs;
   uint8_t* d_qcodes; uint8_t* d_tcodes;        // residue codes of the last SUBMATRIX dp
   float* d_H; uint32_t* d_P; float* d_S;       // planes (d_S only for SIM_MATRIX / HMAP2)
+  float* d_sabs = nullptr;                     // per pair max |S|, left by hmap2_apply_kernel (the exact-order kernel's rounding margin)
+  bool sabs_valid = false;                     // ... and whether it describes the resident d_S
   aln::PairResult* d_res;
   int32_t* d_table32;                          // 32x32 int substitution table (fast path)
   float* d_tablef;                             // 32x32 float table (exact path / getSim)

@@ -1478,7 +1478,9 @@ int launch_dp_exact_blocked(aln_batch* b) {
     float* d_smax = nullptr;
     float smax_const = 0.f;
     if (sub) { for (float v : b->h_table) smax_const = std::max(smax_const, std::fabs(v)); }
-    else if (prune) {
+    else if (prune && b->sabs_valid && ctx->hints.exact_debug != 2) {
+      d_smax = b->d_sabs;                                  // left by hmap2_apply_kernel with the plane (exact_debug 2 borrows the array: own copy then)
+    } else if (prune) {
       d_smax = b->d_xscratch + tiled_floats * (size_t)b->n_pairs;
       hipLaunchKernelGGL(plane_absmax_kernel, dim3(b->n_pairs), dim3(256), 0, ctx->stream, b->d_pairs, b->d_S, d_smax);
       ALN_HIP_CHECK(ctx, hipGetLastError());

@@ -200,22 +200,52 @@ __global__ __launch_bounds__(128) void hmap2_stats_kernel(const PairDesc* __rest
   }
 }
 
+// Four consecutive elements of a row per thread (rows are 32-byte aligned: ld is a multiple of 8).  The pass also leaves max |S| of
+// the pair (every element the DP can read) for the exact-order kernel's rounding margin — one more reduction here instead of
+// one more pass over 16 GB there: |x| as an unsigned word orders like the float, a NaN sorts above everything (and then
+// nothing is skipped, as it must be).
+constexpr int kApplyRows = 16;
 __global__ __launch_bounds__(256) void hmap2_apply_kernel(const PairDesc* __restrict__ pairs, float* __restrict__ Sbase,
-                                                          const float* __restrict__ stats, float shift) {
+                                                          const float* __restrict__ stats, float shift, unsigned int* __restrict__ absmax) {
   const PairDesc pd = pairs[blockIdx.z];
   float* S = Sbase + pd.plane_off;
   const int Q = pd.Q, T = pd.T, ld = pd.ld;
   int i0 = 1, i1 = Q - 1, j0 = 1, j1 = T - 1;
   const bool whole = (i0 >= i1 || j0 >= j1);
   const float avg = stats[2 * blockIdx.z], sd = stats[2 * blockIdx.z + 1];
-  const int i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
-  if (i >= Q || j >= T) return;
-  float x = S[(size_t)i * ld + j];
-  const bool in_norm = whole || (i >= i0 && i < i1 && j >= j0 && j < j1);
-  if (in_norm) { x -= avg; x /= sd; }
-  // shift_elements is called with the same (1..rows-1) bounds and applies the same fallback (hmath.h:81-92)
-  if (in_norm) x = x + shift;
-  S[(size_t)i * ld + j] = x;
+  const int jb = (blockIdx.x * 256 + threadIdx.x) * 4;
+  unsigned int mx = 0u;
+  // kApplyRows rows per workgroup: one atomic per workgroup, not per wave and row (16 M atomics on 1024 words cost 23 ms)
+  for (int i = blockIdx.y * kApplyRows; i < (blockIdx.y + 1) * kApplyRows && i < Q; ++i) {
+    if (jb >= T) break;
+    float4* p4 = reinterpret_cast<float4*>(S + (size_t)i * ld + jb);       // jb + 3 < ld: pad columns are rewritten unchanged
+    float4 v4 = *p4;
+    float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = jb + u;
+      if (j < T) {
+        float x = v[u];
+        const bool in_norm = whole || (i >= i0 && i < i1 && j >= j0 && j < j1);
+        if (in_norm) { x -= avg; x /= sd; }
+        // shift_elements is called with the same (1..rows-1) bounds and applies the same fallback (hmath.h:81-92)
+        if (in_norm) x = x + shift;
+        v[u] = x;
+        const unsigned int a = __float_as_uint(x) & 0x7FFFFFFFu;
+        mx = a > mx ? a : mx;
+      }
+    }
+    *p4 = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  for (int o = 32; o; o >>= 1) { const unsigned int other = (unsigned int)__shfl_xor((int)mx, o); mx = other > mx ? other : mx; }
+  __shared__ unsigned int red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int a = red[0] > red[1] ? red[0] : red[1], c = red[2] > red[3] ? red[2] : red[3];
+    const unsigned int m = a > c ? a : c;
+    if (m) atomicMax(&absmax[blockIdx.z], m);
+  }
 }
 
 // host entry: profiles (pool order, sentinels included) -> d_S for every pair of the batch
@@ -245,10 +275,14 @@ int launch_sim_hmap2(aln_batch* b, const aln_sim* sim) {
   if (sim->normalize) {
     hipLaunchKernelGGL(hmap2_stats_kernel, dim3(b->n_pairs), dim3(128), 0, ctx->stream, b->d_pairs, b->d_S, d_stats);
     HTRY(hipGetLastError());
-    dim3 g3((b->maxT + 255) / 256, b->maxQ, b->n_pairs);
-    hipLaunchKernelGGL(hmap2_apply_kernel, g3, dim3(256), 0, ctx->stream, b->d_pairs, b->d_S, d_stats, -sim->zero_shift);
+    if (!b->d_sabs) HTRY(hipMalloc((void**)&b->d_sabs, (size_t)std::max(b->n_pairs, 1) * 4));
+    HTRY(hipMemsetAsync(b->d_sabs, 0, (size_t)std::max(b->n_pairs, 1) * 4, ctx->stream));
+    dim3 g3((b->maxT + 1023) / 1024, (b->maxQ + kApplyRows - 1) / kApplyRows, b->n_pairs);
+    hipLaunchKernelGGL(hmap2_apply_kernel, g3, dim3(256), 0, ctx->stream, b->d_pairs, b->d_S, d_stats, -sim->zero_shift,
+                       reinterpret_cast<unsigned int*>(b->d_sabs));
     HTRY(hipGetLastError());
   }
+  b->sabs_valid = sim->normalize != 0;
   HTRY(hipStreamSynchronize(ctx->stream));
 #undef HTRY
   cleanup();
