@@ -374,6 +374,9 @@ int aln_hmap2_gap_arrays(const float* t_sse, int64_t n, float gap_init, float ga
 /* ---- measurement hooks ---------------------------------------------------------------------- */
 /* Context hint "exact_debug" = 1: the exact-order tiled kernel (config 3) counts, per wave, the far candidate chunks it tested
  * against their bounds and the ones it could skip: out4 = {deletion chunks tested, skipped, insertion chunks tested, skipped}.
+ * "exact_debug" = 2: the same four words hold how long the kernel's waves ran instead — {sum, longest, bitwise NOT of the
+ * shortest, number of waves}, in units of 1024 s_memtime ticks — and the library lists the slowest pairs on stderr (that is how
+ * a degenerate all-NaN pair was found to bound a 1024-pair launch).
  * (No reference counterpart: the reference scans every candidate, dpmatrix.h:453-480.) */
 int aln_batch_last_exact_stats(const aln_batch* b, uint64_t* out4);
 /* Milliseconds the device spent in the DP kernel(s) of the last aln_batch_dp, from HIP events recorded on
